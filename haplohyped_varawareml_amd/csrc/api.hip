@@ -1,0 +1,567 @@
+// api.hip — C ABI of libhhgt.so (see include/hhgt.h): context, orchestration of the kernel stages,
+// error reporting.  No CPU fallback anywhere: every compute entry point needs a HIP device.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+
+static thread_local char g_err[512] = "";
+
+void hhgt_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *hhgt_last_error(void) { return g_err; }
+extern "C" const char *hhgt_version(void) { return "hhgt 0.1 (gfx950)"; }
+
+extern "C" int hhgt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap) return HHGT_OK;
+    if (p) {
+        hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        hhgt_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return HHGT_ERR_HIP;
+    }
+    cap = want;
+    return HHGT_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+#define TRY(expr)                      \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != HHGT_OK) return _rc; \
+    } while (0)
+
+extern "C" int hhgt_ctx_create(int device, hhgt_ctx **out)
+{
+    if (!out) return HHGT_ERR_ARG;
+    *out = nullptr;
+    int n = hhgt_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        hhgt_set_error("no usable HIP device (count=%d, requested=%d): libhhgt has no CPU path", n, device);
+        return HHGT_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    hhgt_ctx *c = new hhgt_ctx();
+    c->device = device;
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device));
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        hhgt_set_error("device %d is %s; libhhgt carries gfx950 code objects only", device, c->prop.gcnArchName);
+        delete c;
+        return HHGT_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(DevCounters), hipHostMallocDefault));
+    TRY(c->counters.ensure(sizeof(DevCounters)));
+    TRY(c->region.ensure(sizeof(RegionFilter)));
+    *out = c;
+    return HHGT_OK;
+}
+
+extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    DevBuf *bufs[] = {&c->slots, &c->counts, &c->prefix, &c->nl, &c->scan_tmp, &c->l_soff, &c->l_lend, &c->l_pos,
+                      &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff,
+                      &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_off,
+                      &c->counters, &c->region, &c->lz_scratch, &c->lz_csize, &c->fr_bsize, &c->fr_csize,
+                      &c->fr_flags, &c->dec_bad};
+    for (DevBuf *b : bufs) b->release();
+    if (c->h_counters) hipHostFree(c->h_counters);
+    for (auto &p : c->pending) {
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    delete c;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------
+static hipEvent_t get_event(hhgt_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+StageTimer::StageTimer(hhgt_ctx *c, hipStream_t s, int stage_) : ctx(c), st(s), stage(stage_)
+{
+    if (ctx->profiling) {
+        a = get_event(ctx);
+        b = get_event(ctx);
+        hipEventRecord(a, st);
+    }
+}
+
+void StageTimer::stop()
+{
+    if (a) {
+        hipEventRecord(b, st);
+        ctx->pending.push_back({stage, a, b});
+        a = b = nullptr;
+    }
+}
+
+int hhgt_profile_collect(hhgt_ctx *c)
+{
+    for (auto &p : c->pending) {
+        hipEventSynchronize(p.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->stage_ms[p.stage] += ms;
+            c->stage_launches[p.stage] += 1;
+        }
+        c->event_pool.push_back(p.a);
+        c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_profile_enable(hhgt_ctx *c, int on)
+{
+    if (!c) return HHGT_ERR_ARG;
+    c->profiling = on ? 1 : 0;
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_profile_reset(hhgt_ctx *c)
+{
+    if (!c) return HHGT_ERR_ARG;
+    hhgt_profile_collect(c);
+    for (int i = 0; i < HHGT_N_STAGES; ++i) {
+        c->stage_ms[i] = 0;
+        c->stage_launches[i] = 0;
+    }
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_profile_read(hhgt_ctx *c, double *ms, uint64_t *launches)
+{
+    if (!c) return HHGT_ERR_ARG;
+    hhgt_profile_collect(c);
+    for (int i = 0; i < HHGT_N_STAGES; ++i) {
+        if (ms) ms[i] = c->stage_ms[i];
+        if (launches) launches[i] = c->stage_launches[i];
+    }
+    return HHGT_OK;
+}
+
+// ---- layout ---------------------------------------------------------------------------------------
+static int make_layout(const hhgt_layout *lay, LayoutDev *L)
+{
+    if (!lay || lay->n_samples < 0) {
+        hhgt_set_error("layout: bad n_samples");
+        return HHGT_ERR_ARG;
+    }
+    L->S = (uint32_t)lay->n_samples;
+    L->v_capacity = lay->v_capacity;
+    if (lay->vc == 0) {
+        L->Vc = lay->v_capacity ? lay->v_capacity : TILE_V;
+    } else {
+        L->Vc = (uint64_t)lay->vc;
+    }
+    if (L->Vc % TILE_V) {
+        hhgt_set_error("layout: variants per chunk (%llu) must be a multiple of %d (dense: v_capacity)",
+                       (unsigned long long)L->Vc, TILE_V);
+        return HHGT_ERR_ARG;
+    }
+    if (lay->v_capacity % L->Vc) {
+        hhgt_set_error("layout: v_capacity must be a multiple of vc");
+        return HHGT_ERR_ARG;
+    }
+    if (lay->sc == 0) {
+        L->Sc = L->S ? L->S : 1;
+        L->sc_log2 = 31;
+        L->n_sc = 1;
+    } else {
+        uint32_t sc = (uint32_t)lay->sc;
+        if (sc & (sc - 1)) {
+            hhgt_set_error("layout: sc must be a power of two");
+            return HHGT_ERR_ARG;
+        }
+        L->Sc = sc;
+        uint32_t lg = 0;
+        while ((1u << lg) < sc) ++lg;
+        L->sc_log2 = lg;
+        L->n_sc = (L->S + sc - 1) / sc;
+        if (L->n_sc == 0) L->n_sc = 1;
+    }
+    return HHGT_OK;
+}
+
+extern "C" uint64_t hhgt_layout_bytes(const hhgt_layout *lay)
+{
+    LayoutDev L;
+    if (make_layout(lay, &L) != HHGT_OK) return 0;
+    return (uint64_t)L.n_sc * L.Sc * L.v_capacity * 2ull;
+}
+
+extern "C" uint64_t hhgt_layout_offset(const hhgt_layout *lay, uint32_t s, uint64_t v)
+{
+    LayoutDev L;
+    if (make_layout(lay, &L) != HHGT_OK) return ~0ull;
+    return layout_offset(L, s, v);
+}
+
+static int parse_region_host(const char *region, RegionFilter *rf)
+{
+    memset(rf, 0, sizeof(*rf));
+    if (!region || !*region) return HHGT_OK;
+    const char *colon = strrchr(region, ':');
+    size_t clen = strlen(region);
+    if (colon && colon[1] >= '0' && colon[1] <= '9') {
+        char *p;
+        long long b = strtoll(colon + 1, &p, 10), e = 0x7fffffffffffffffLL;
+        while (*p == ',') p++;
+        if (*p == '-' && p[1]) e = strtoll(p + 1, &p, 10);
+        clen = (size_t)(colon - region);
+        rf->has_range = 1;
+        rf->beg = b;
+        rf->end = e;
+    }
+    if (clen == 0 || clen >= sizeof(rf->contig)) {
+        hhgt_set_error("region '%s': contig name empty or longer than 63 bytes", region);
+        return HHGT_ERR_ARG;
+    }
+    memcpy(rf->contig, region, clen);
+    rf->contig_len = (int)clen;
+    return HHGT_OK;
+}
+
+// ---- encode ---------------------------------------------------------------------------------------
+#define MAX_CHROM_RUNS 4096u
+
+extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
+                                const hhgt_layout *lay, uint64_t v_base, void *d_G, uint32_t *d_start,
+                                uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_stats *stats,
+                                void *stream)
+{
+    if (!c) return HHGT_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    LayoutDev L;
+    TRY(make_layout(lay, &L));
+    if (nbytes >= 0xFFFFFFF0ull) {
+        hhgt_set_error("encode: text block of %llu bytes; split it below 4 GiB at a line boundary",
+                       (unsigned long long)nbytes);
+        return HHGT_ERR_ARG;
+    }
+    if (nbytes && (!d_text || (reinterpret_cast<uintptr_t>(d_text) & 15u))) {
+        hhgt_set_error("encode: d_text must be a 16-byte aligned device pointer");
+        return HHGT_ERR_ARG;
+    }
+    if (L.S > 0 && !d_G) {
+        hhgt_set_error("encode: d_G is NULL");
+        return HHGT_ERR_ARG;
+    }
+    RegionFilter rf;
+    TRY(parse_region_host(region, &rf));
+    c->run_first_kept.clear();
+    c->run_names.clear();
+    if (nbytes == 0) return HHGT_OK;
+
+    const uint8_t *text = static_cast<const uint8_t *>(d_text);
+    DevCounters *cnt = c->counters.as<DevCounters>();
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));
+    HIP_TRY(hipMemcpyAsync(c->region.p, &rf, sizeof(rf), hipMemcpyHostToDevice, st));
+
+    // ---- stage: newline index
+    const uint32_t n_regions = (uint32_t)((nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION);
+    TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
+    TRY(c->counts.ensure((size_t)n_regions * 4));
+    TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
+    TRY(c->scan_tmp.ensure(scan_tmp_elems(n_regions) * 4));
+    uint32_t n_lines = 0;
+    {
+        StageTimer t(c, st, HHGT_STAGE_INDEX);
+        TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, cnt, st));
+        TRY(launch_scan_exclusive_u32(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), n_regions,
+                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+        // line count back to the host: sizes every later launch
+        c->h_counters->n_lines = 0;
+        c->h_counters->err_density = 0;
+        HIP_TRY(hipMemcpyAsync(&c->h_counters->n_lines, c->prefix.as<uint32_t>() + n_regions, 4,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&c->h_counters->err_density, &cnt->err_density, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_lines = (uint32_t)(c->h_counters->n_lines & 0xFFFFFFFFull);
+        if (c->h_counters->err_density) {
+            hhgt_set_error("encode: more than %u newlines inside one %u-byte region (not VCF text)", INDEX_CAP,
+                           INDEX_REGION);
+            return HHGT_ERR_LINE_DENSITY;
+        }
+        TRY(c->nl.ensure(((size_t)n_lines + 1) * 4));
+        TRY(c->scan_tmp.ensure(scan_tmp_elems(n_lines) * 4));
+        TRY(launch_compact_newlines(c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(),
+                                    n_regions, c->nl.as<uint32_t>(), st));
+        t.stop();
+    }
+    if (stats) stats->n_lines = n_lines;
+    if (n_lines == 0) return HHGT_OK;
+
+    // ---- stage: fixed columns, filter, kept-record compaction
+    const size_t nl4 = ((size_t)n_lines + 1) * 4;
+    DevBuf *per_line[] = {&c->l_soff, &c->l_lend, &c->l_pos, &c->l_refalt, &c->l_flags, &c->l_keep,
+                          &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff, &c->k_lend, &c->k_meta,
+                          &c->redo_list, &c->redo_flag};
+    for (DevBuf *b : per_line) TRY(b->ensure(nl4));
+    TRY(c->run_first.ensure(MAX_CHROM_RUNS * 8));
+    TRY(c->run_off.ensure(MAX_CHROM_RUNS * 4));
+    {
+        StageTimer t(c, st, HHGT_STAGE_FIXED);
+        TRY(launch_parse_fixed(text, nbytes, c->nl.as<uint32_t>(), n_lines, c->region.as<RegionFilter>(), L.S,
+                               c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(),
+                               c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(), c->l_keep.as<uint32_t>(),
+                               c->l_cnew.as<uint32_t>(), cnt, st));
+        TRY(launch_scan_exclusive_u32(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), n_lines,
+                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+        TRY(launch_scan_exclusive_u32(c->l_cnew.as<uint32_t>(), c->l_crun.as<uint32_t>(), n_lines,
+                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+        HIP_TRY(hipMemsetAsync(c->redo_flag.p, 0, (size_t)n_lines * 4, st));
+        TRY(launch_compact_kept(c->nl.as<uint32_t>(), n_lines, c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(),
+                                c->l_pos.as<uint32_t>(), c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(),
+                                c->l_kidx.as<uint32_t>(), c->l_crun.as<uint32_t>(), c->k_soff.as<uint32_t>(),
+                                c->k_lend.as<uint32_t>(), c->k_meta.as<uint32_t>(), c->redo_list.as<uint32_t>(),
+                                c->run_first.as<uint64_t>(), c->run_off.as<uint32_t>(), MAX_CHROM_RUNS, v_base,
+                                L.v_capacity, d_start, d_stop, d_ref, d_alt, cnt, st));
+        t.stop();
+    }
+    // ---- stage: GT tiles (fixed-width lines)
+    if (L.S > 0) {
+        StageTimer t(c, st, HHGT_STAGE_ENCODE);
+        TRY(launch_encode_tiles(text, nbytes, c->k_soff.as<uint32_t>(), c->k_meta.as<uint32_t>(), n_lines, v_base,
+                                L, static_cast<int8_t *>(d_G), c->redo_list.as<uint32_t>(),
+                                c->redo_flag.as<uint32_t>(), cnt, st));
+        t.stop();
+        StageTimer t2(c, st, HHGT_STAGE_GENERAL);
+        TRY(launch_encode_general(text, nbytes, c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(),
+                                  c->k_meta.as<uint32_t>(), c->redo_list.as<uint32_t>(), v_base, L,
+                                  static_cast<int8_t *>(d_G), cnt, c->prop.multiProcessorCount, st));
+        t2.stop();
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const DevCounters &h = *c->h_counters;
+    if (stats) {
+        stats->n_lines = n_lines;
+        stats->n_records = h.n_records;
+        stats->n_kept = h.n_kept;
+        stats->n_drop_region = h.n_drop_region;
+        stats->n_drop_filter = h.n_drop_filter;
+        stats->n_haploid_padded = h.n_haploid;
+        stats->n_malformed = h.n_malformed;
+        stats->n_general_lines = h.n_general;
+        stats->n_chrom_runs = h.n_chrom_runs;
+    }
+    if (h.n_malformed) {
+        hhgt_set_error("Error parsing VCF file: %llu malformed record(s) (too few columns, bad POS, FORMAT without GT)",
+                       (unsigned long long)h.n_malformed);
+        return HHGT_ERR_MALFORMED;
+    }
+    if (v_base + h.n_kept > L.v_capacity) {
+        hhgt_set_error("encode: %llu kept records at v_base %llu exceed v_capacity %llu",
+                       (unsigned long long)h.n_kept, (unsigned long long)v_base, (unsigned long long)L.v_capacity);
+        return HHGT_ERR_CAPACITY;
+    }
+    // CHROM runs (names are a few bytes each; read back lazily but while the text is still resident)
+    uint32_t n_runs = (uint32_t)(h.n_chrom_runs < MAX_CHROM_RUNS ? h.n_chrom_runs : MAX_CHROM_RUNS);
+    if (n_runs) {
+        std::vector<uint64_t> first(n_runs);
+        std::vector<uint32_t> off(n_runs);
+        HIP_TRY(hipMemcpy(first.data(), c->run_first.p, n_runs * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(off.data(), c->run_off.p, n_runs * 4, hipMemcpyDeviceToHost));
+        for (uint32_t r = 0; r < n_runs; ++r) {
+            char buf[64];
+            size_t take = nbytes - off[r] < 63 ? (size_t)(nbytes - off[r]) : 63;
+            HIP_TRY(hipMemcpy(buf, text + off[r], take, hipMemcpyDeviceToHost));
+            size_t l = 0;
+            while (l < take && buf[l] != '\t' && buf[l] != '\n') ++l;
+            c->run_first_kept.push_back(first[r]);
+            c->run_names.emplace_back(buf, l);
+        }
+    }
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_encode_chrom_runs(hhgt_ctx *c, uint32_t max_runs, uint64_t *first_kept, char *names,
+                                      uint32_t *n_runs)
+{
+    if (!c || !n_runs) return HHGT_ERR_ARG;
+    uint32_t n = (uint32_t)c->run_first_kept.size();
+    *n_runs = n;
+    if (n > max_runs) n = max_runs;
+    for (uint32_t r = 0; r < n; ++r) {
+        if (first_kept) first_kept[r] = c->run_first_kept[r];
+        if (names) {
+            memset(names + (size_t)r * 32, 0, 32);
+            size_t l = c->run_names[r].size() < 31 ? c->run_names[r].size() : 31;
+            memcpy(names + (size_t)r * 32, c->run_names[r].data(), l);
+        }
+    }
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_pad_tail(hhgt_ctx *c, const hhgt_layout *lay, uint64_t v_end, uint64_t vcol_begin,
+                             uint64_t vcol_end, void *d_G, void *stream)
+{
+    if (!c || !d_G) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    LayoutDev L;
+    TRY(make_layout(lay, &L));
+    if (v_end > L.v_capacity || vcol_end > L.v_capacity / L.Vc) {
+        hhgt_set_error("pad_tail: range outside the layout");
+        return HHGT_ERR_ARG;
+    }
+    return launch_pad_tail(L, v_end, vcol_begin, vcol_end, static_cast<int8_t *>(d_G),
+                           reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- compress -------------------------------------------------------------------------------------
+static int check_codec_args(uint64_t chunk_nbytes, int typesize, int blocksize, int format)
+{
+    if (typesize < 1 || typesize > 255 || blocksize < 16 || blocksize > 65536 || blocksize % typesize ||
+        chunk_nbytes == 0 || chunk_nbytes >= 0x7fffffffull || (format != HHGT_BLOSC1 && format != HHGT_BLOSC2)) {
+        hhgt_set_error("compress: bad arguments (chunk_nbytes=%llu typesize=%d blocksize=%d format=%d)",
+                       (unsigned long long)chunk_nbytes, typesize, blocksize, format);
+        return HHGT_ERR_ARG;
+    }
+    return HHGT_OK;
+}
+
+// c-blosc never writes a blocksize larger than the chunk (its decoder rejects such headers)
+static int effective_blocksize(uint64_t chunk_nbytes, int typesize, int blocksize)
+{
+    if ((uint64_t)blocksize > chunk_nbytes) {
+        blocksize = (int)chunk_nbytes;
+        if (typesize > 1 && blocksize >= typesize) blocksize -= blocksize % typesize;
+    }
+    return blocksize > 0 ? blocksize : 1;
+}
+
+static void codec_geometry(uint64_t chunk_nbytes, int typesize, int blocksize, uint32_t *nblocks, uint32_t *nwaves,
+                           size_t *slot_bytes)
+{
+    const bool split = typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128;
+    *nblocks = (uint32_t)((chunk_nbytes + blocksize - 1) / blocksize);
+    *nwaves = split ? (uint32_t)typesize : 1u;
+    size_t max_stream = split ? (size_t)blocksize / typesize : (size_t)blocksize;
+    if (split && chunk_nbytes % blocksize && chunk_nbytes % blocksize > max_stream) max_stream = chunk_nbytes % blocksize;
+    *slot_bytes = lz4_slot_bytes((int)max_stream);
+}
+
+extern "C" uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize)
+{
+    if (check_codec_args(chunk_nbytes, typesize, blocksize, HHGT_BLOSC2) != HHGT_OK) return 0;
+    // a chunk never exceeds nbytes + 32 (memcpyed form)
+    return n_chunks * (chunk_nbytes + 32);
+}
+
+extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
+                                    int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
+                                    uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream)
+{
+    if (!c || !d_src || !d_dst || !d_chunk_off) return HHGT_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    TRY(check_codec_args(chunk_nbytes, typesize, blocksize, format));
+    if (total_bytes) *total_bytes = 0;
+    if (n_chunks == 0) return HHGT_OK;
+    blocksize = effective_blocksize(chunk_nbytes, typesize, blocksize);
+    uint32_t nblocks, nwaves;
+    size_t slot;
+    codec_geometry(chunk_nbytes, typesize, blocksize, &nblocks, &nwaves, &slot);
+    const uint64_t n_streams = n_chunks * nblocks * nwaves;
+    TRY(c->lz_scratch.ensure((size_t)n_streams * slot));
+    TRY(c->lz_csize.ensure((size_t)n_streams * 4));
+    TRY(c->fr_bsize.ensure((size_t)n_chunks * nblocks * 4));
+    TRY(c->fr_csize.ensure(((size_t)n_chunks + 1) * 8));
+    TRY(c->fr_flags.ensure((size_t)n_chunks * 4));
+    {
+        StageTimer t(c, st, HHGT_STAGE_LZ4);
+        TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize,
+                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), st));
+        t.stop();
+    }
+    {
+        StageTimer t(c, st, HHGT_STAGE_FRAME);
+        TRY(launch_frame(c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(),
+                         static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize, format,
+                         c->fr_bsize.as<uint32_t>(), c->fr_csize.as<uint64_t>(), static_cast<uint8_t *>(d_dst),
+                         dst_cap, d_chunk_off, c->fr_flags.as<uint32_t>(), st));
+        t.stop();
+    }
+    if (total_bytes) {
+        uint64_t tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, d_chunk_off + n_chunks, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *total_bytes = tot;
+        if (tot > dst_cap) {
+            hhgt_set_error("compress: need %llu bytes, dst_cap is %llu", (unsigned long long)tot,
+                           (unsigned long long)dst_cap);
+            return HHGT_ERR_CAPACITY;
+        }
+    }
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_decompress_chunks(hhgt_ctx *c, const void *d_src, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                                      uint64_t chunk_nbytes, int typesize, int blocksize, void *d_dst,
+                                      uint64_t *n_bad, void *stream)
+{
+    if (!c || !d_src || !d_dst || !d_chunk_off) return HHGT_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    TRY(check_codec_args(chunk_nbytes, typesize, blocksize, HHGT_BLOSC2));
+    if (n_bad) *n_bad = 0;
+    if (n_chunks == 0) return HHGT_OK;
+    blocksize = effective_blocksize(chunk_nbytes, typesize, blocksize);
+    TRY(c->dec_bad.ensure(8));
+    HIP_TRY(hipMemsetAsync(c->dec_bad.p, 0, 8, st));
+    {
+        StageTimer t(c, st, HHGT_STAGE_DECODE);
+        TRY(launch_decode(static_cast<const uint8_t *>(d_src), d_chunk_off, n_chunks, chunk_nbytes, typesize,
+                          blocksize, static_cast<uint8_t *>(d_dst), c->dec_bad.as<unsigned long long>(), st));
+        t.stop();
+    }
+    if (n_bad) {
+        uint64_t nb = 0;
+        HIP_TRY(hipMemcpyAsync(&nb, c->dec_bad.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *n_bad = nb;
+    }
+    return HHGT_OK;
+}

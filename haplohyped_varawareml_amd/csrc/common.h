@@ -1,0 +1,171 @@
+// common.h — internal declarations shared by the libhhgt.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/hhgt.h"
+
+#define HHGT_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void hhgt_set_error(const char *fmt, ...);
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            hhgt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                      \
+            return HHGT_ERR_HIP;                                                           \
+        }                                                                                  \
+    } while (0)
+
+// ---- per-line flag bits (index/fixed-column stage) --------------------------------------------
+enum : uint32_t {
+    LF_RECORD = 1u,        // data line (non-empty, not '#')
+    LF_KEEP = 2u,          // passed region + isSNP
+    LF_FAST = 4u,          // FORMAT == "GT" and sample region is exactly 4*S-1 bytes
+    LF_MALFORMED = 8u,
+    LF_DROP_REGION = 16u,
+    LF_DROP_FILTER = 32u,
+    LF_CHROM_NEW = 64u,    // CHROM differs from the previous data line
+};
+
+// device-side counters written by the kernels of one hhgt_encode_text call
+struct DevCounters {
+    unsigned long long n_lines;
+    unsigned long long n_records;
+    unsigned long long n_kept;
+    unsigned long long n_drop_region;
+    unsigned long long n_drop_filter;
+    unsigned long long n_haploid;
+    unsigned long long n_malformed;
+    unsigned long long n_general;    // entries in the redo (variable-width) list
+    unsigned long long n_chrom_runs;
+    unsigned long long err_density;  // newline-slot overflow
+    unsigned long long pad[6];
+};
+
+struct RegionFilter {
+    char contig[64];
+    int contig_len;   // 0 = no filter
+    int has_range;
+    long long beg, end;  // 1-based inclusive
+};
+
+// index stage geometry: one wave scans INDEX_REGION bytes, at most INDEX_CAP newlines in it
+#define INDEX_REGION 16384u
+#define INDEX_CAP 1024u
+
+// encode tile geometry
+#define TILE_V 128
+#define TILE_S 256
+
+struct LayoutDev {
+    uint32_t S;
+    uint32_t sc_log2;    // log2(samples per chunk); 31 = dense (single sample-chunk)
+    uint32_t n_sc;       // sample-chunks per chunk column
+    uint32_t Sc;         // samples per chunk (dense: S)
+    uint64_t Vc;         // variants per chunk (dense: v_capacity)
+    uint64_t v_capacity;
+};
+
+// workspace buffer that only grows
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct hhgt_ctx {
+    int device = 0;
+    hipDeviceProp_t prop;
+    // index / fixed / keep workspaces
+    DevBuf slots, counts, prefix, nl, scan_tmp;
+    DevBuf l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_kidx, l_cnew, l_crun;
+    DevBuf k_soff, k_lend, k_meta, redo_list, redo_flag, run_first, run_off;
+    DevBuf counters;       // DevCounters
+    DevBuf region;         // RegionFilter
+    // compress workspaces
+    DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad;
+    // pinned host mirror for counters
+    DevCounters *h_counters = nullptr;
+    // last encode's chrom runs (host)
+    std::vector<uint64_t> run_first_kept;
+    std::vector<std::string> run_names;
+    // profiling
+    int profiling = 0;
+    double stage_ms[HHGT_N_STAGES] = {0};
+    uint64_t stage_launches[HHGT_N_STAGES] = {0};
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// RAII-ish stage timer: records events around a stage when profiling is on
+struct StageTimer {
+    hhgt_ctx *ctx;
+    hipStream_t st;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(hhgt_ctx *c, hipStream_t s, int stage_);
+    void stop();
+};
+int hhgt_profile_collect(hhgt_ctx *ctx);
+
+// ---- launchers (defined in the .hip files) ------------------------------------------------------
+// scan.hip
+int launch_scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp,
+                              size_t tmp_elems, hipStream_t st);
+size_t scan_tmp_elems(uint64_t n);
+
+// index.hip
+int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
+                          uint32_t n_regions, DevCounters *d_cnt, hipStream_t st);
+int launch_compact_newlines(const uint32_t *d_slots, const uint32_t *d_counts, const uint32_t *d_prefix,
+                            uint32_t n_regions, uint32_t *d_nl, hipStream_t st);
+int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, uint32_t n_lines,
+                       const RegionFilter *d_region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
+                       uint32_t *l_pos, uint32_t *l_refalt, uint32_t *l_flags, uint32_t *l_keep,
+                       uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st);
+int launch_compact_kept(const uint32_t *d_nl, uint32_t n_lines, const uint32_t *l_soff, const uint32_t *l_lend,
+                        const uint32_t *l_pos, const uint32_t *l_refalt, const uint32_t *l_flags,
+                        const uint32_t *l_kidx, const uint32_t *l_crun, uint32_t *k_soff, uint32_t *k_lend,
+                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint32_t *run_off,
+                        uint32_t max_runs, uint64_t v_base, uint64_t v_capacity, uint32_t *d_start,
+                        uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, hipStream_t st);
+
+// encode.hip
+int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_meta,
+                        uint32_t n_lines_bound, uint64_t v_base, LayoutDev lay, int8_t *d_G,
+                        uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st);
+int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_lend,
+                          const uint32_t *k_meta, const uint32_t *redo_list, uint64_t v_base, LayoutDev lay,
+                          int8_t *d_G, DevCounters *d_cnt, int n_cu, hipStream_t st);
+int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, int8_t *d_G,
+                    hipStream_t st);
+
+// lz4.hip
+size_t lz4_slot_bytes(int neblock);
+int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+                      hipStream_t st);
+// frame.hip
+int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src,
+                 uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
+                 uint32_t *d_bstart, uint64_t *d_chunk_csize, uint8_t *d_dst, uint64_t dst_cap,
+                 uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st);
+int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_chunks, uint64_t chunk_nbytes,
+                  int typesize, int blocksize, uint8_t *d_dst, unsigned long long *d_bad, hipStream_t st);
+
+// layout helper shared by host and device
+static inline __host__ __device__ uint64_t layout_offset(const LayoutDev &L, uint32_t s, uint64_t v)
+{
+    uint64_t vcol = v / L.Vc, vin = v - vcol * L.Vc;
+    uint32_t scol = (L.sc_log2 >= 31) ? 0u : (s >> L.sc_log2);
+    uint32_t sin = s - scol * L.Sc;
+    return (((vcol * L.n_sc + scol) * L.Sc + sin) * L.Vc + vin) * 2ull;
+}

@@ -1,0 +1,365 @@
+// encode.hip — GT text -> int8 genotype tiles on gfx950 (CDNA4).
+//
+// Replaces the reference's per-record, per-sample loop
+//   var.getGenotypes(gt); phase1 = (int8)gt[0]; phase2 = (int8)gt[1]   /root/reference/cpp/parse_vcf.cpp:45-52
+//   '.' -> -9, else allele index                                        /root/reference/cpp/vcfpp.h:546-588
+// (and htslib's vcf_parse_format GT tokeniser behind it) by ONE pass over the sample columns of all
+// kept lines that emits every sample at once as G[s, v', 2].
+//
+// k_encode_tiles (fixed-width lines "a|b\t" x S — the 1000G shape): a 256-thread workgroup owns a
+//   128-variant x 256-sample tile.  Wave w reads 32 lines; lane l reads 16 contiguous bytes (4 samples)
+//   of each line, so every wave-load is a coalesced 1 KiB run of raw GT bytes.  Each lane packs its
+//   4 samples x 32 variants in registers, the tile is transposed through a 64 KiB XOR-swizzled LDS
+//   image (conflict-free ds_write_b128 / ds_read_b128) and leaves as 256-byte sample-row segments.
+//   HBM roofline: algorithmic bytes per variant = 4*S read + 2*S written; no MFMA (byte work).
+// k_encode_general (anything else: GT:DP columns, multi-digit alleles, haploid calls ...): one wave
+//   per line, tab-rank by ballot/prefix over 1 KiB pieces, htslib GT rule per field.
+#include "common.h"
+
+// -------------------------------------------------------------------------------------------------
+// one "a|b\t" field in a dword (little endian: a, sep, b, terminator) -> h0 | h1 << 8 ; bit 31 = not
+// a fixed-width field this path may decode
+__device__ __forceinline__ uint32_t parse_field_exact(uint32_t x)
+{
+    uint32_t a = x & 0xFFu, sep = (x >> 8) & 0xFFu, b = (x >> 16) & 0xFFu, t = x >> 24;
+    uint32_t da = a - '0', db = b - '0';
+    bool ok = (sep == '|' || sep == '/') && t == '\t' && (da < 10u || a == '.') && (db < 10u || b == '.');
+    uint32_t h0 = a == '.' ? 0xF7u : da;  // -9 as int8
+    uint32_t h1 = b == '.' ? 0xF7u : db;
+    return (h0 & 0xFFu) | ((h1 & 0xFFu) << 8) | (ok ? 0u : 0x80000000u);
+}
+
+__device__ __forceinline__ uint32_t parse_field(uint32_t x)
+{
+    // common case: both alleles are '0' or '1', separator '|', terminator '\t'
+    if ((x & 0xFFFEFFFEu) == 0x09307C30u) return (x & 1u) | ((x >> 8) & 0x100u);
+    return parse_field_exact(x);
+}
+
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+
+#define FILL_FIELD 0x09307C30u  // "0|0\t"
+
+__global__ __launch_bounds__(256, 2) void k_encode_tiles(const uint8_t *__restrict__ text, uint64_t n,
+                                                         const uint32_t *__restrict__ k_soff,
+                                                         const uint32_t *__restrict__ k_meta, uint64_t v_base,
+                                                         LayoutDev lay, int8_t *__restrict__ G,
+                                                         uint32_t *__restrict__ redo_list,
+                                                         uint32_t *__restrict__ redo_flag, DevCounters *cnt)
+{
+    __shared__ uint4 tile[TILE_S * 16];  // 256 rows x 256 B, 16-byte slots XOR-swizzled by (row >> 2) & 7
+    const uint32_t n_kept = (uint32_t)cnt->n_kept;
+    const uint64_t gv0 = (v_base / TILE_V + blockIdx.x) * (uint64_t)TILE_V;  // first global column of tile
+    const long long k0 = (long long)gv0 - (long long)v_base;                 // batch-local kept index of it
+    if (k0 >= (long long)n_kept || gv0 >= lay.v_capacity) return;
+    const uint32_t s0 = blockIdx.y * TILE_S;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t S = lay.S;
+    const uint32_t ls = s0 + 4u * lane;                       // first sample of this lane
+    const uint32_t nval = ls >= S ? 0u : (S - ls >= 4u ? 4u : S - ls);  // samples this lane owns
+    const uint32_t last_q = (S - 1u >= ls && S - 1u < ls + 4u) ? S - 1u - ls : 4u;  // which dword is sample S-1
+
+    uint32_t acc[4][16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[q][c] = 0;
+
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint4 raw[8];
+        bool lvalid[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long k = k0 + (long long)(w * 32u + g * 8 + j);
+            bool valid = k >= 0 && k < (long long)n_kept;
+            uint32_t meta = 0, soff = 0;
+            if (valid) {
+                meta = k_meta[k];
+                soff = k_soff[k];
+            }
+            valid = valid && (meta & LF_FAST);
+            lvalid[j] = valid;
+            uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
+            if (valid && nval) {
+                const uint64_t off = (uint64_t)soff + 4ull * ls;
+                if (nval == 4u && off + 16ull <= n) {
+                    u32x4_unaligned t = *reinterpret_cast<const u32x4_unaligned *>(text + off);
+                    v = make_uint4(t.x, t.y, t.z, t.w);
+                } else {
+                    uint32_t d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t x = FILL_FIELD;
+                        if ((uint32_t)q < nval) {
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) {
+                                uint64_t idx = off + (uint64_t)(q * 4 + bb);
+                                uint32_t c = idx < n ? text[idx] : (uint32_t)'\t';
+                                x = (x & ~(0xFFu << (bb * 8))) | (c << (bb * 8));
+                            }
+                        }
+                        d[q] = x;
+                    }
+                    v = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            }
+            raw[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t x[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+            uint32_t bad = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t xx = x[q];
+                // the last sample of a line is terminated by the line end, not by a tab (the region
+                // length check LF_FAST already pinned where it ends)
+                if ((uint32_t)q == last_q) xx = (xx & 0x00FFFFFFu) | 0x09000000u;
+                uint32_t r = parse_field(xx);
+                bad |= r;
+                const int col = g * 8 + j;
+                acc[q][col >> 1] |= (r & 0xFFFFu) << ((col & 1) * 16);
+            }
+            if (lvalid[j]) {
+                unsigned long long bm = __ballot((bad & 0x80000000u) != 0u);
+                if (bm != 0ull && lane == 0) {
+                    const uint32_t k = (uint32_t)(k0 + (long long)(w * 32u + g * 8 + j));
+                    if (atomicExch(&redo_flag[k], 1u) == 0u) {
+                        unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
+                        redo_list[slot] = k;
+                    }
+                }
+            }
+        }
+    }
+    // registers -> LDS (sample-major rows).  Wave w owns byte columns [64w, 64w+64) of every row.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t row = 4u * lane + q;
+        const uint32_t swz = (row >> 2) & 7u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t slot = (w * 4u + c) ^ swz;
+            tile[row * 16u + slot] = make_uint4(acc[q][c * 4 + 0], acc[q][c * 4 + 1], acc[q][c * 4 + 2], acc[q][c * 4 + 3]);
+        }
+    }
+    __syncthreads();
+    // LDS -> HBM: each row leaves as one contiguous 256-byte run (16 lanes x 16 B)
+    const uint32_t c16 = threadIdx.x & 15u;
+    const uint64_t vcol = gv0 / lay.Vc, vin = gv0 - vcol * lay.Vc;
+    const long long kfirst = k0 + (long long)c16 * 8;  // batch-local kept index of this lane's 8 columns
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const uint32_t row = it * 16u + (threadIdx.x >> 4);
+        const uint32_t s = s0 + row;
+        if (s >= S) continue;
+        const uint32_t swz = (row >> 2) & 7u;
+        uint4 v = tile[row * 16u + (c16 ^ swz)];
+        const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
+        const uint32_t sin = s - scol * lay.Sc;
+        int8_t *dst = G + ((((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull) + c16 * 16u;
+        if (kfirst >= 0) {
+            *reinterpret_cast<uint4 *>(dst) = v;
+        } else if (kfirst + 8 > 0) {  // tile straddles v_base: keep the columns the previous batch wrote
+            uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (kfirst + e >= 0)
+                    reinterpret_cast<uint16_t *>(dst)[e] = (uint16_t)(d[e >> 1] >> ((e & 1) * 16));
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// htslib vcf_parse_format GT rule (see oracle/vcf_oracle.c parse_gt for the restatement it mirrors)
+__device__ __forceinline__ uint32_t parse_gt_bytes(const uint8_t *__restrict__ text, uint32_t p, uint32_t lim,
+                                                   uint32_t *n_alleles)
+{
+    int l = 0;
+    int vals[2] = {-9, -9};
+    for (;;) {
+        uint32_t c = p < lim ? text[p] : 0u;
+        if (c == '.') {
+            ++p;
+            if (l < 2) vals[l] = -9;
+            ++l;
+        } else if (c - '0' < 10u) {
+            long long v = 0;
+            while (p < lim) {
+                uint32_t d = (uint32_t)text[p] - '0';
+                if (d >= 10u) break;
+                v = v * 10 + d;
+                if (v > 0x7fffffffLL) v &= 0x7fffffffLL;
+                ++p;
+            }
+            if (l < 2) vals[l] = (int)v;
+            ++l;
+        } else
+            break;
+        c = p < lim ? text[p] : 0u;
+        if (c != '|' && c != '/') break;
+        ++p;
+    }
+    if (l == 0) {
+        vals[0] = -9;
+        l = 1;
+    }
+    *n_alleles = (uint32_t)l;
+    return ((uint32_t)vals[0] & 0xFFu) | (((uint32_t)vals[1] & 0xFFu) << 8);
+}
+
+__global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restrict__ text, uint64_t n,
+                                                        const uint32_t *__restrict__ k_soff,
+                                                        const uint32_t *__restrict__ k_lend,
+                                                        const uint32_t *__restrict__ k_meta,
+                                                        const uint32_t *__restrict__ redo_list, uint64_t v_base,
+                                                        LayoutDev lay, int8_t *__restrict__ G, DevCounters *cnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t n_redo = (uint32_t)cnt->n_general;
+    const uint32_t S = lay.S;
+    uint32_t haploid = 0, malformed = 0;
+    for (uint32_t idx = wave; idx < n_redo; idx += n_waves) {
+        const uint32_t k = redo_list[idx];
+        const uint32_t soff = k_soff[k], lend = k_lend[k], gtidx = k_meta[k] >> 8;
+        const uint64_t v = v_base + k;
+        if (v >= lay.v_capacity) continue;
+        const uint64_t vcol = v / lay.Vc, vin = v - vcol * lay.Vc;
+        const uint32_t rs = soff - 1u;  // the 9th tab: every sample field is preceded by a tab in [rs, lend)
+        uint32_t tabs_before = 0;
+        for (uint32_t base = rs; base < lend; base += 1024u) {
+            const uint32_t b0 = base + 16u * lane;
+            uint32_t m = 0;
+            if (b0 < lend) {
+                for (uint32_t j = 0; j < 16u; ++j) {
+                    uint32_t p = b0 + j;
+                    if (p < lend && text[p] == '\t') m |= 1u << j;
+                }
+            }
+            uint32_t c = __popc(m), inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(inc, d, 64);
+                if (lane >= (uint32_t)d) inc += t;
+            }
+            uint32_t f = tabs_before + inc - c;
+            while (m) {
+                int j = __ffs(m) - 1;
+                m &= m - 1;
+                const uint32_t s = f++;
+                if (s >= S) continue;  // surplus columns are not decoded (the oracle ignores them too)
+                uint32_t p = b0 + (uint32_t)j + 1u;
+                bool missing = false;
+                for (uint32_t gsk = 0; gsk < gtidx; ++gsk) {  // skip to the GT sub-field
+                    while (p < lend && text[p] != ':' && text[p] != '\t') ++p;
+                    if (p < lend && text[p] == ':') ++p;
+                    else {
+                        missing = true;
+                        break;
+                    }
+                }
+                uint32_t na = 1, hv = 0xF7F7u;
+                if (!missing) {
+                    // the sub-field ends at ':' or at the column's tab; both stop the GT rule
+                    hv = parse_gt_bytes(text, p, lend, &na);
+                }
+                if (na == 1u) ++haploid;
+                const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
+                const uint32_t sin = s - scol * lay.Sc;
+                int8_t *dst = G + ((((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull);
+                *reinterpret_cast<uint16_t *>(dst) = (uint16_t)hv;
+            }
+            tabs_before += __shfl(inc, 63, 64);
+        }
+        if (tabs_before < S && lane == 0) ++malformed;  // fewer sample columns than the header declares
+    }
+    // one atomic per wave
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) haploid += __shfl_down(haploid, d, 64);
+    if (lane == 0) {
+        if (haploid) atomicAdd(&cnt->n_haploid, (unsigned long long)haploid);
+        if (malformed) atomicAdd(&cnt->n_malformed, (unsigned long long)malformed);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// zero columns [c0, c1) (variant index inside the chunk column) of rows [r0, r1) (sample index inside
+// the padded sample axis) of chunk column vcol
+__global__ __launch_bounds__(256) void k_zero_rect(LayoutDev lay, uint64_t vcol, uint32_t r0, uint32_t r1,
+                                                   uint64_t c0, uint64_t c1, int8_t *__restrict__ G)
+{
+    const uint32_t r = r0 + blockIdx.y;
+    if (r >= r1) return;
+    const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (r >> lay.sc_log2);
+    const uint32_t sin = r - scol * lay.Sc;
+    int8_t *row = G + (((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc) * 2ull;
+    const uint64_t b0 = c0 * 2ull, b1 = c1 * 2ull;
+    // 16-byte segments
+    const uint64_t seg0 = b0 / 16ull, seg1 = (b1 + 15ull) / 16ull;
+    for (uint64_t sgm = seg0 + blockIdx.x * blockDim.x + threadIdx.x; sgm < seg1;
+         sgm += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = sgm * 16ull, hi = lo + 16ull;
+        if (lo >= b0 && hi <= b1)
+            *reinterpret_cast<uint4 *>(row + lo) = make_uint4(0, 0, 0, 0);
+        else
+            for (uint64_t b = lo < b0 ? b0 : lo; b < (hi > b1 ? b1 : hi); ++b) row[b] = 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_meta,
+                        uint32_t n_lines_bound, uint64_t v_base, LayoutDev lay, int8_t *d_G,
+                        uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st)
+{
+    if (n_lines_bound == 0 || lay.S == 0) return HHGT_OK;
+    uint64_t tiles_v = ((v_base % TILE_V) + n_lines_bound + TILE_V - 1) / TILE_V;
+    uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
+    hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
+                       k_meta, v_base, lay, d_G, redo_list, redo_flag, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_lend,
+                          const uint32_t *k_meta, const uint32_t *redo_list, uint64_t v_base, LayoutDev lay,
+                          int8_t *d_G, DevCounters *d_cnt, int n_cu, hipStream_t st)
+{
+    if (lay.S == 0) return HHGT_OK;
+    hipLaunchKernelGGL(k_encode_general, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
+                       k_meta, redo_list, v_base, lay, d_G, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, int8_t *d_G,
+                    hipStream_t st)
+{
+    const uint32_t S_pad = lay.n_sc * lay.Sc;
+    // (a) variant padding of the last touched chunk column
+    if (v_end % lay.Vc) {
+        uint64_t vcol = v_end / lay.Vc;
+        uint64_t c0 = v_end - vcol * lay.Vc, c1 = lay.Vc;
+        if (vcol < vcol_end && vcol >= vcol_begin && S_pad) {
+            uint64_t segs = ((c1 - c0) * 2 + 15) / 16 + 1;
+            uint32_t gx = (uint32_t)((segs + 255) / 256);
+            if (gx > 1024) gx = 1024;
+            hipLaunchKernelGGL(k_zero_rect, dim3(gx, S_pad), dim3(256), 0, st, lay, vcol, 0u, S_pad, c0, c1, d_G);
+        }
+    }
+    // (b) sample padding rows of every touched chunk column
+    if (S_pad > lay.S) {
+        for (uint64_t vcol = vcol_begin; vcol < vcol_end; ++vcol) {
+            uint64_t segs = (lay.Vc * 2 + 15) / 16 + 1;
+            uint32_t gx = (uint32_t)((segs + 255) / 256);
+            if (gx > 1024) gx = 1024;
+            hipLaunchKernelGGL(k_zero_rect, dim3(gx, S_pad - lay.S), dim3(256), 0, st, lay, vcol, lay.S, S_pad, 0ull,
+                               lay.Vc, d_G);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}

@@ -1,0 +1,332 @@
+// index.hip — line framing and fixed-column parse on device-resident VCF text (gfx950).
+//
+// Replaces, for a whole block of text at once, what the reference does one record at a time:
+//   tbx_itr_next -> raw text line                 /root/reference/cpp/vcfpp.h:1468
+//   vcf_parse1: CHROM POS ID REF ALT ... FORMAT   /root/reference/cpp/vcfpp.h:1471  (htslib)
+//   BcfRecord::isSNP filter                       /root/reference/cpp/vcfpp.h:990-1000
+//   Start()/End()/REF()/ALT()                     /root/reference/cpp/vcfpp.h:1118-1133,1142-1151
+//   region restriction (tabix contig[:beg-end])   /root/reference/cpp/vcfpp.h:1424-1451
+//
+// Stage 1 (k_index_newlines): ONE streaming read of the text, 16 B per lane, coalesced; each wave
+//   owns a 16 KiB region and records the newline positions it finds in a private slot array.
+//   HBM bound: algorithmic bytes = nbytes read + 4 B per line written.
+// Stage 2 (k_compact_newlines): prefix over per-region counts -> dense nl[] array (O(lines)).
+// Stage 3 (k_parse_fixed): one lane per line walks the 9 fixed columns (O(F) bytes per line,
+//   F ~ 60-300 B, versus the ~10 KB sample region that only the encode stage reads).
+// Stage 4 (k_compact_kept): kept records are compacted (exclusive scan of keep flags) and the
+//   per-record table (start, stop, ref, alt) is written at v_base + k.
+#include "common.h"
+
+__device__ __forceinline__ uint32_t nl_mask4(uint32_t x)
+{
+    // exact per-byte "== '\n'" -> bit k set for byte k
+    uint32_t t = x ^ 0x0A0A0A0Au;
+    uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 where byte == 0
+    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+
+// grid: ceil(n_regions / 4) blocks of 256 threads; wave w of block b scans region 4b + w.
+__global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restrict__ text, uint64_t n,
+                                                        uint32_t *__restrict__ slots,
+                                                        uint32_t *__restrict__ counts, uint32_t n_regions,
+                                                        DevCounters *cnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= n_regions) return;
+    // a text that does not end in '\n' gets a virtual newline at position n
+    const bool virt = n > 0 && text[n - 1] != '\n';
+    const uint64_t rbase = (uint64_t)r * INDEX_REGION;
+    uint32_t *my = slots + (size_t)r * INDEX_CAP;
+    uint32_t wcount = 0;
+    bool overflow = false;
+    uint32_t masks[INDEX_REGION / 1024];
+    // issue all loads first (16 independent 16 B loads per lane), then resolve
+#pragma unroll
+    for (int it = 0; it < (int)(INDEX_REGION / 1024); ++it) {
+        uint64_t g0 = rbase + (uint64_t)it * 1024u + lane * 16u;
+        uint32_t m = 0;
+        if (g0 + 16 <= n) {
+            uint4 v = *reinterpret_cast<const uint4 *>(text + g0);
+            m = nl_mask4(v.x) | (nl_mask4(v.y) << 4) | (nl_mask4(v.z) << 8) | (nl_mask4(v.w) << 12);
+        } else if (g0 <= n) {
+            for (int j = 0; j < 16; ++j) {
+                uint64_t g = g0 + j;
+                if (g < n) {
+                    if (text[g] == '\n') m |= 1u << j;
+                } else if (g == n && virt)
+                    m |= 1u << j;
+            }
+        }
+        masks[it] = m;
+    }
+#pragma unroll
+    for (int it = 0; it < (int)(INDEX_REGION / 1024); ++it) {
+        uint32_t m = masks[it];
+        if (__ballot(m != 0) == 0ull) continue;  // wave-uniform: long lines mostly skip
+        uint32_t c = __popc(m);
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += t;
+        }
+        uint32_t idx = wcount + inc - c;
+        uint32_t g0 = (uint32_t)(rbase + (uint64_t)it * 1024u + lane * 16u);
+        while (m) {
+            int j = __ffs(m) - 1;
+            m &= m - 1;
+            if (idx < INDEX_CAP) my[idx] = g0 + (uint32_t)j;
+            else overflow = true;
+            ++idx;
+        }
+        wcount += __shfl(inc, 63, 64);
+    }
+    if (__ballot(overflow) != 0ull && lane == 0) atomicAdd(&cnt->err_density, 1ull);
+    if (lane == 0) counts[r] = wcount < INDEX_CAP ? wcount : INDEX_CAP;
+}
+
+// one thread per region: copy its slot entries to their final place
+__global__ __launch_bounds__(256) void k_compact_newlines(const uint32_t *__restrict__ slots,
+                                                          const uint32_t *__restrict__ counts,
+                                                          const uint32_t *__restrict__ prefix,
+                                                          uint32_t n_regions, uint32_t *__restrict__ nl)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    uint32_t c = counts[r], p = prefix[r];
+    const uint32_t *my = slots + (size_t)r * INDEX_CAP;
+    for (uint32_t k = 0; k < c; ++k) nl[p + k] = my[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed columns: one lane per line
+__global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__ text, uint64_t n,
+                                                     const uint32_t *__restrict__ nl, uint32_t n_lines,
+                                                     const RegionFilter *__restrict__ rf, uint32_t S,
+                                                     uint32_t *__restrict__ l_soff, uint32_t *__restrict__ l_lend,
+                                                     uint32_t *__restrict__ l_pos, uint32_t *__restrict__ l_refalt,
+                                                     uint32_t *__restrict__ l_flags, uint32_t *__restrict__ l_keep,
+                                                     uint32_t *__restrict__ l_cnew, DevCounters *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t flags = 0;
+    if (i < n_lines) {
+        uint32_t s = i ? nl[i - 1] + 1u : 0u;
+        uint32_t e = nl[i];
+        if (e > s && text[e - 1] == '\r') --e;  // bgzf_getline strips a trailing CR
+        uint32_t soff = e, pos0 = 0, refalt = 0, gtidx = 0;
+        if (e > s && text[s] != '#') {
+            flags = LF_RECORD;
+            // walk the first 9 tab-separated fields
+            uint32_t fs[10];
+            uint32_t nf = 0;
+            uint32_t p = s;
+            fs[0] = s;
+            while (p < e && nf < 9) {
+                if (text[p] == '\t') fs[++nf] = p + 1;
+                ++p;
+            }
+            // nf = number of tabs found (<= 9); field k spans [fs[k], fs[k+1]-1) for k < nf
+            bool bad = false;
+            uint32_t fe[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) fe[k] = (uint32_t)k < nf ? fs[k + 1] - 1u : e;
+            if (nf < 7 || (S > 0 && nf < 9)) bad = true;
+            if (!bad) {
+                // POS
+                unsigned long long pos = 0;
+                if (fe[1] == fs[1]) bad = true;
+                for (uint32_t q = fs[1]; q < fe[1]; ++q) {
+                    uint32_t c = text[q];
+                    if (c < '0' || c > '9') {
+                        bad = true;
+                        break;
+                    }
+                    pos = pos * 10ull + (c - '0');
+                }
+                bool in_region = true;
+                if (!bad && rf->contig_len > 0) {
+                    uint32_t cl = fe[0] - fs[0];
+                    in_region = cl == (uint32_t)rf->contig_len;
+                    for (uint32_t q = 0; in_region && q < cl; ++q)
+                        in_region = text[fs[0] + q] == (uint8_t)rf->contig[q];
+                    if (in_region && rf->has_range)
+                        in_region = (long long)pos >= rf->beg && (long long)pos <= rf->end;
+                }
+                if (!bad) {
+                    if (!in_region)
+                        flags |= LF_DROP_REGION;
+                    else {
+                        // isSNP (cpp/vcfpp.h:990-1000): |REF| <= 1, n_allele <= 2, ALT in {A,C,G,T}
+                        uint32_t reflen = fe[3] - fs[3], altlen = fe[4] - fs[4];
+                        uint32_t a = altlen == 1 ? text[fs[4]] : 0;
+                        bool snp = reflen == 1 && altlen == 1 && (a == 'A' || a == 'C' || a == 'G' || a == 'T');
+                        if (!snp)
+                            flags |= LF_DROP_FILTER;
+                        else {
+                            pos0 = (uint32_t)(pos - 1ull);  // vcfpp.h:1118-1121
+                            refalt = (uint32_t)text[fs[3]] | (a << 8);
+                            if (S > 0) {
+                                // GT key index inside FORMAT (bcf_get_genotypes looks the key up)
+                                uint32_t q = fs[8], k = 0;
+                                bool found = false;
+                                while (q <= fe[8]) {
+                                    uint32_t q2 = q;
+                                    while (q2 < fe[8] && text[q2] != ':') ++q2;
+                                    if (q2 - q == 2 && text[q] == 'G' && text[q + 1] == 'T') {
+                                        found = true;
+                                        break;
+                                    }
+                                    ++k;
+                                    q = q2 + 1;
+                                }
+                                if (!found) bad = true;  // vcfpp.h:550-552 "genotypes not present"
+                                gtidx = k;
+                                soff = fs[9];
+                                if (!bad) {
+                                    flags |= LF_KEEP;
+                                    if (k == 0 && fe[8] - fs[8] == 2 && e - soff == 4u * S - 1u) flags |= LF_FAST;
+                                }
+                            } else {
+                                flags |= LF_KEEP;
+                            }
+                        }
+                    }
+                }
+            }
+            if (bad) flags = LF_RECORD | LF_MALFORMED;
+            // CHROM run boundary: compare with the previous data line's CHROM
+            bool cnew = true;
+            if (i > 0) {
+                uint32_t ps = i > 1 ? nl[i - 2] + 1u : 0u;
+                uint32_t pe = nl[i - 1];
+                if (pe > ps && text[ps] != '#') {
+                    uint32_t q = 0;
+                    cnew = false;
+                    for (;;) {
+                        uint32_t a = fs[0] + q < e ? text[fs[0] + q] : '\t';
+                        uint32_t b = ps + q < pe ? text[ps + q] : '\t';
+                        if (a != b) {
+                            cnew = true;
+                            break;
+                        }
+                        if (a == '\t') break;
+                        ++q;
+                    }
+                }
+            }
+            if (cnew) flags |= LF_CHROM_NEW;
+        }
+        l_soff[i] = soff;
+        l_lend[i] = e;
+        l_pos[i] = pos0;
+        l_refalt[i] = refalt | (gtidx << 16);
+        l_flags[i] = flags;
+        l_keep[i] = (flags & LF_KEEP) ? 1u : 0u;
+        l_cnew[i] = (flags & LF_CHROM_NEW) ? 1u : 0u;
+    }
+    // statistics: one atomic per wave per category
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long b;
+    b = __ballot(flags & LF_RECORD);
+    if (lane == 0 && b) atomicAdd(&cnt->n_records, (unsigned long long)__popcll(b));
+    b = __ballot(flags & LF_DROP_REGION);
+    if (lane == 0 && b) atomicAdd(&cnt->n_drop_region, (unsigned long long)__popcll(b));
+    b = __ballot(flags & LF_DROP_FILTER);
+    if (lane == 0 && b) atomicAdd(&cnt->n_drop_filter, (unsigned long long)__popcll(b));
+    b = __ballot(flags & LF_MALFORMED);
+    if (lane == 0 && b) atomicAdd(&cnt->n_malformed, (unsigned long long)__popcll(b));
+}
+
+// one thread per line; kept lines scatter to their compacted slot
+__global__ __launch_bounds__(256) void k_compact_kept(
+    const uint32_t *__restrict__ nl, uint32_t n_lines, const uint32_t *__restrict__ l_soff,
+    const uint32_t *__restrict__ l_lend, const uint32_t *__restrict__ l_pos, const uint32_t *__restrict__ l_refalt,
+    const uint32_t *__restrict__ l_flags, const uint32_t *__restrict__ l_kidx, const uint32_t *__restrict__ l_crun,
+    uint32_t *__restrict__ k_soff, uint32_t *__restrict__ k_lend, uint32_t *__restrict__ k_meta,
+    uint32_t *__restrict__ redo_list, uint64_t *__restrict__ run_first, uint32_t *__restrict__ run_off,
+    uint32_t max_runs, uint64_t v_base, uint64_t v_capacity, uint32_t *__restrict__ d_start,
+    uint32_t *__restrict__ d_stop, uint8_t *__restrict__ d_ref, uint8_t *__restrict__ d_alt, DevCounters *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lines) return;
+    const uint32_t flags = l_flags[i];
+    if (flags & LF_CHROM_NEW) {
+        // run id = number of CHROM_NEW flags before this line; the run's first kept index is the
+        // exclusive kept-prefix here; its name is the CHROM field at the start of this line
+        uint32_t rid = l_crun[i];
+        if (rid < max_runs) {
+            run_first[rid] = l_kidx[i];
+            run_off[rid] = i ? nl[i - 1] + 1u : 0u;
+        }
+    }
+    if (i == n_lines - 1) {
+        cnt->n_kept = (unsigned long long)l_kidx[n_lines];
+        cnt->n_chrom_runs = (unsigned long long)l_crun[n_lines];
+    }
+    if (!(flags & LF_KEEP)) return;
+    const uint32_t k = l_kidx[i];
+    const uint64_t v = v_base + k;
+    const uint32_t ra = l_refalt[i];
+    k_soff[k] = l_soff[i];
+    k_lend[k] = l_lend[i];
+    k_meta[k] = (flags & LF_FAST) | ((ra >> 16) << 8);  // bit2 = FAST, bits 8.. = GT key index
+    if (!(flags & LF_FAST)) {
+        unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
+        redo_list[slot] = k;
+    }
+    if (v < v_capacity) {
+        uint32_t pos0 = l_pos[i];
+        if (d_start) d_start[v] = pos0;
+        if (d_stop) d_stop[v] = pos0 + 1u;  // vcfpp.h:1124-1127 with |REF| == 1
+        if (d_ref) d_ref[v] = (uint8_t)(ra & 0xFFu);
+        if (d_alt) d_alt[v] = (uint8_t)((ra >> 8) & 0xFFu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
+                          uint32_t n_regions, DevCounters *d_cnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_index_newlines, dim3((n_regions + 3) / 4), dim3(256), 0, st, d_text, n, d_slots,
+                       d_counts, n_regions, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_compact_newlines(const uint32_t *d_slots, const uint32_t *d_counts, const uint32_t *d_prefix,
+                            uint32_t n_regions, uint32_t *d_nl, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_compact_newlines, dim3((n_regions + 255) / 256), dim3(256), 0, st, d_slots, d_counts,
+                       d_prefix, n_regions, d_nl);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, uint32_t n_lines,
+                       const RegionFilter *d_region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
+                       uint32_t *l_pos, uint32_t *l_refalt, uint32_t *l_flags, uint32_t *l_keep,
+                       uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st)
+{
+    if (n_lines == 0) return HHGT_OK;
+    hipLaunchKernelGGL(k_parse_fixed, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, n_lines,
+                       d_region, S, l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_cnew, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_compact_kept(const uint32_t *d_nl, uint32_t n_lines, const uint32_t *l_soff, const uint32_t *l_lend,
+                        const uint32_t *l_pos, const uint32_t *l_refalt, const uint32_t *l_flags,
+                        const uint32_t *l_kidx, const uint32_t *l_crun, uint32_t *k_soff, uint32_t *k_lend,
+                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint32_t *run_off,
+                        uint32_t max_runs, uint64_t v_base, uint64_t v_capacity, uint32_t *d_start,
+                        uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, hipStream_t st)
+{
+    if (n_lines == 0) return HHGT_OK;
+    hipLaunchKernelGGL(k_compact_kept, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_nl, n_lines, l_soff,
+                       l_lend, l_pos, l_refalt, l_flags, l_kidx, l_crun, k_soff, k_lend, k_meta, redo_list,
+                       run_first, run_off, max_runs, v_base, v_capacity, d_start, d_stop, d_ref, d_alt, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}

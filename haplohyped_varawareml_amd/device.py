@@ -1,0 +1,224 @@
+"""Thin Python layer over the C ABI (include/hhgt.h): torch tensors provide device memory and the
+stream; every computation happens inside libhhgt.so's HIP kernels."""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BLOSC1, BLOSC2, EncodeStats, HhgtError, Layout, check
+
+# default on-disk geometry: one HDF5 chunk = 64 samples x 16384 variants x 2 haplotypes (2 MiB);
+# one Blosc2 block = one sample row of the chunk (32 KiB); typesize 2 = one diploid call
+DEFAULT_SC = 64
+DEFAULT_VC = 16384
+DEFAULT_TYPESIZE = 2
+
+
+def make_layout(n_samples, v_capacity, sc=DEFAULT_SC, vc=DEFAULT_VC):
+    """chunk-tiled layout; v_capacity is rounded up to a whole number of chunk columns
+    (dense: to a multiple of 128)."""
+    if vc:
+        v_capacity = -(-max(int(v_capacity), 1) // vc) * vc
+    else:
+        v_capacity = -(-max(int(v_capacity), 1) // 128) * 128
+    return Layout(int(n_samples), int(sc), int(vc), 0, int(v_capacity))
+
+
+def layout_bytes(lay):
+    return int(_lib.load().hhgt_layout_bytes(C.byref(lay)))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@dataclass
+class EncodeResult:
+    G: torch.Tensor            # uint8 view of the chunk-tiled int8 matrix
+    layout: Layout
+    start: torch.Tensor
+    stop: torch.Tensor
+    ref: torch.Tensor
+    alt: torch.Tensor
+    n_kept: int
+    stats: dict
+    chrom_runs: list = field(default_factory=list)   # [(first_kept_index, name)]
+
+    def dense(self):
+        """int8 [S, n_kept, 2] torch tensor (device) gathered out of the chunk-tiled buffer."""
+        lay = self.layout
+        S, n = lay.n_samples, self.n_kept
+        if lay.sc == 0 and lay.vc == 0:
+            return self.G.view(torch.int8).view(max(S, 1), lay.v_capacity, 2)[:S, :n]
+        Sc, Vc = lay.sc or max(S, 1), lay.vc or lay.v_capacity
+        n_sc = -(-S // Sc) if lay.sc else 1
+        n_vc = lay.v_capacity // Vc
+        g = self.G.view(torch.int8).view(n_vc, n_sc, Sc, Vc, 2).permute(1, 2, 0, 3, 4)
+        return g.reshape(n_sc * Sc, n_vc * Vc, 2)[:S, :n]
+
+
+class Context:
+    """One per (process, GPU).  Wraps hhgt_ctx."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise HhgtError(-6, "no HIP device visible to torch: libhhgt has no CPU path")
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        check(self.lib.hhgt_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hhgt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- encode --------------------------------------------------------------------------------
+    def encode_text(self, text, n_samples, region="", layout=None, v_base=0, out=None):
+        """text: uint8 CUDA tensor holding whole VCF lines.  Returns EncodeResult; pass out=
+        (a previous EncodeResult) to append at v_base into the same buffers."""
+        assert text.is_cuda and text.dtype == torch.uint8 and text.is_contiguous()
+        nbytes = text.numel()
+        with torch.cuda.device(self.device):
+            if out is None:
+                if layout is None:
+                    # capacity from a line-count bound: a kept line has at least 16 + 2*S bytes
+                    bound = nbytes // (16 + 2 * max(n_samples, 0)) + 1
+                    layout = make_layout(n_samples, bound)
+                G = torch.zeros(max(layout_bytes(layout), 16), dtype=torch.uint8, device=self.device)
+                cap = layout.v_capacity
+                start = torch.zeros(cap, dtype=torch.int32, device=self.device)
+                stop = torch.zeros(cap, dtype=torch.int32, device=self.device)
+                ref = torch.zeros(cap, dtype=torch.uint8, device=self.device)
+                alt = torch.zeros(cap, dtype=torch.uint8, device=self.device)
+                out = EncodeResult(G, layout, start, stop, ref, alt, 0, {})
+            st = EncodeStats()
+            rc = self.lib.hhgt_encode_text(self.h, _ptr(text), nbytes, (region or "").encode(),
+                                           C.byref(out.layout), int(v_base), _ptr(out.G), _ptr(out.start),
+                                           _ptr(out.stop), _ptr(out.ref), _ptr(out.alt), C.byref(st), _stream())
+            check(rc)
+            out.stats = st.asdict()
+            out.n_kept = int(v_base) + int(st.n_kept)
+            out.chrom_runs = self.chrom_runs()
+        return out
+
+    def chrom_runs(self):
+        n = C.c_uint32(0)
+        check(self.lib.hhgt_encode_chrom_runs(self.h, 0, None, None, C.byref(n)))
+        if n.value == 0:
+            return []
+        first = np.zeros(n.value, np.uint64)
+        names = np.zeros((n.value, 32), np.uint8)
+        check(self.lib.hhgt_encode_chrom_runs(self.h, n.value, first.ctypes.data, names.ctypes.data, C.byref(n)))
+        return [(int(first[i]), bytes(names[i]).rstrip(b"\0").decode()) for i in range(n.value)]
+
+    def pad_tail(self, res, v_end=None, vcol_begin=0, vcol_end=None):
+        lay = res.layout
+        Vc = lay.vc or lay.v_capacity
+        v_end = res.n_kept if v_end is None else v_end
+        if vcol_end is None:
+            vcol_end = -(-max(v_end, 1) // Vc)
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_pad_tail(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end),
+                                         _ptr(res.G), _stream()))
+
+    # ---- codec ---------------------------------------------------------------------------------
+    def compress(self, src, chunk_nbytes, typesize=DEFAULT_TYPESIZE, blocksize=None, fmt=BLOSC2,
+                 dst=None, chunk_off=None, sync=True):
+        """src: uint8 CUDA tensor of n_chunks * chunk_nbytes bytes.
+        -> (dst uint8 tensor, chunk_off int64 tensor [n_chunks+1], total_bytes or None)"""
+        assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+        chunk_nbytes = int(chunk_nbytes)
+        assert src.numel() % chunk_nbytes == 0
+        n_chunks = src.numel() // chunk_nbytes
+        if blocksize is None:
+            blocksize = min(chunk_nbytes, 32768)
+            blocksize -= blocksize % typesize
+        with torch.cuda.device(self.device):
+            cap = int(self.lib.hhgt_compress_bound(n_chunks, chunk_nbytes, typesize, blocksize))
+            if cap == 0:
+                check(-1)
+            if dst is None:
+                dst = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            if chunk_off is None:
+                chunk_off = torch.zeros(n_chunks + 1, dtype=torch.int64, device=self.device)
+            total = C.c_uint64(0)
+            check(self.lib.hhgt_compress_chunks(self.h, _ptr(src), n_chunks, chunk_nbytes, typesize, blocksize,
+                                                fmt, _ptr(dst), dst.numel(), _ptr(chunk_off),
+                                                C.byref(total) if sync else None, _stream()))
+        return dst, chunk_off, (int(total.value) if sync else None)
+
+    def decompress(self, src, chunk_off, n_chunks, chunk_nbytes, typesize=DEFAULT_TYPESIZE, blocksize=None,
+                   dst=None):
+        """-> (dst uint8 tensor [n_chunks*chunk_nbytes], n_bad)"""
+        if blocksize is None:
+            blocksize = min(int(chunk_nbytes), 32768)
+            blocksize -= blocksize % typesize
+        with torch.cuda.device(self.device):
+            if dst is None:
+                dst = torch.empty(int(n_chunks) * int(chunk_nbytes), dtype=torch.uint8, device=self.device)
+            bad = C.c_uint64(0)
+            check(self.lib.hhgt_decompress_chunks(self.h, _ptr(src), _ptr(chunk_off), int(n_chunks),
+                                                  int(chunk_nbytes), typesize, blocksize, _ptr(dst),
+                                                  C.byref(bad), _stream()))
+        return dst, int(bad.value)
+
+    # ---- synthetic workloads (bench / test tooling) -----------------------------------------------
+    def synth_fixed(self, contig, table, n_samples, seed, v_first=0, with_header=True, names=None):
+        """Render a fixed-width synthetic shard directly in HBM.  -> (text uint8 tensor, nbytes)"""
+        from . import synth
+        lib = self.lib
+        if not hasattr(lib, "_synth_bound"):
+            lib.hhgt_synth_render_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                    C.c_char_p, C.c_int, C.c_uint64, C.c_void_p]
+            lib._synth_bound = True
+        S = int(n_samples)
+        pos = table["pos"]
+        V = len(pos)
+        head = synth.header_text(contig, names or synth.sample_names(S)) if with_header else b""
+        ll = synth.fixed_line_lengths(contig, pos, S)
+        off = np.zeros(V + 1, dtype=np.uint64)
+        off[0] = len(head)
+        off[1:] = len(head) + np.cumsum(ll).astype(np.uint64)
+        nbytes = int(off[-1])
+        with torch.cuda.device(self.device):
+            text = torch.empty(nbytes + 16, dtype=torch.uint8, device=self.device)
+            if head:
+                text[:len(head)] = torch.frombuffer(bytearray(head), dtype=torch.uint8).to(self.device)
+            d_off = torch.from_numpy(off.view(np.int64)).to(self.device)
+            d_pos = torch.from_numpy(pos.view(np.int32)).to(self.device)
+            d_ref = torch.from_numpy(table["ref"]).to(self.device)
+            d_alt = torch.from_numpy(table["alt"]).to(self.device)
+            d_thr = torch.from_numpy(table["thr"].view(np.int32)).to(self.device)
+            check(lib.hhgt_synth_render_fixed(self.h, _ptr(text), nbytes, _ptr(d_off), _ptr(d_pos), _ptr(d_ref),
+                                              _ptr(d_alt), _ptr(d_thr), V, int(v_first), contig.encode(), S,
+                                              int(seed), _stream()))
+            torch.cuda.current_stream().synchronize()
+        return text[:nbytes], nbytes
+
+    # ---- profiling -----------------------------------------------------------------------------
+    def profile(self, on=True):
+        check(self.lib.hhgt_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.hhgt_profile_reset(self.h))
+
+    def profile_read(self):
+        ms = (C.c_double * _lib.N_STAGES)()
+        n = (C.c_uint64 * _lib.N_STAGES)()
+        check(self.lib.hhgt_profile_read(self.h, ms, n))
+        return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.STAGE_NAMES) if n[i]}

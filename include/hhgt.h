@@ -1,0 +1,165 @@
+/*
+ * hhgt.h — C ABI of libhhgt.so: MI355X (gfx950) genotype encode + Blosc2 shuffle/LZ4 chunk compress.
+ *
+ * This is the drop-in boundary for ONE hot path of Jaureguy760/HaploHyped-VarAwareML:
+ *
+ *   reference interface replaced                                       entry point here
+ *   ------------------------------------------------------------------ -------------------------
+ *   VCFLoader::load_vcf            cpp/parse_vcf.cpp:30-71  (pybind11    hhgt_encode_text (+ hhgt_reader_* for
+ *     binding :116-124; per-record GT -> int8 via vcfpp.h:546-588,       files): all samples of a shard in one
+ *     isSNP filter vcfpp.h:990-1000)                                     pass -> int8 G[s, v', 2]
+ *   VCFLoader::load_vcf_without_sample  cpp/parse_vcf.cpp:80-113        hhgt_encode_text with n_samples = 0
+ *   h5py create_dataset(compression=32001,                              hhgt_compress_chunks (byte-shuffle + LZ4
+ *     compression_opts=(2,2,0,0,5,1,2))  src/haplohyped/vcf_to_h5.py:134-135   -> Blosc2-framed chunks), and
+ *     = hdf5plugin Blosc2 filter -> c-blosc2 shuffle + LZ4 block encode  hhgt_decompress_chunks (read side,
+ *                                                                        src/utils/h5_reader.py:37-41)
+ *
+ * Conventions: plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HBM) on the
+ * context's device; everything else is host memory.  `stream` is a hipStream_t passed as void*
+ * (NULL = the null stream).  Every function returns HHGT_OK (0) or a negative HHGT_ERR_* code and
+ * never aborts the process; hhgt_last_error() returns a thread-local message for the last failure
+ * (the reference raises std::runtime_error -> Python RuntimeError, cpp/parse_vcf.cpp:63-66).
+ * There is no CPU fallback: without a usable HIP device every compute entry point fails with
+ * HHGT_ERR_NO_DEVICE.
+ */
+#ifndef HHGT_H
+#define HHGT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HHGT_OK 0
+#define HHGT_ERR_ARG (-1)          /* bad argument                                              */
+#define HHGT_ERR_HIP (-2)          /* a HIP runtime call failed                                 */
+#define HHGT_ERR_CAPACITY (-3)     /* an output buffer is too small                             */
+#define HHGT_ERR_MALFORMED (-4)    /* input text violates the VCF structure the path relies on  */
+#define HHGT_ERR_LINE_DENSITY (-5) /* > 1 newline per 16 bytes on average inside a 16 KiB region */
+#define HHGT_ERR_NO_DEVICE (-6)    /* no HIP device / kernels for this device                   */
+#define HHGT_ERR_IO (-7)           /* file open/read/inflate failure                            */
+
+#define HHGT_BLOSC1 1 /* 16-byte header (c-blosc 1.x), readable by c-blosc2 as well            */
+#define HHGT_BLOSC2 2 /* 32-byte extended header (c-blosc2 2.x chunk)                          */
+
+typedef struct hhgt_ctx hhgt_ctx;
+
+const char *hhgt_version(void);
+const char *hhgt_last_error(void);
+int hhgt_device_count(void);
+
+/* One context per (process, GPU): owns workspaces and timing events.  Not thread-safe; use one
+ * context per host thread (the reference's loader object is stateless, cpp/parse_vcf.cpp:19). */
+int hhgt_ctx_create(int device, hhgt_ctx **out);
+void hhgt_ctx_destroy(hhgt_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Genotype matrix layout in HBM ("chunk-tiled"):
+ *     G[vcol][scol][Sc][Vc][2] int8,  vcol = v / Vc, scol = s / Sc
+ * so every HDF5 chunk (Sc samples x Vc variants x 2 haplotypes, C order) is one contiguous
+ * Sc*Vc*2-byte run and one sample row of a chunk (Vc*2 bytes) is one Blosc2 block.
+ * sc == 0 / vc == 0 select the dense layout G[S][v_capacity][2] (a single chunk).
+ * Constraints: vc % 128 == 0; v_capacity % vc == 0; sc is a power of two (or 0).
+ * Parity definition: G[s, :, 0] == [t[5] for t in load_vcf(vcf, sample_s, chrom)],
+ * G[s, :, 1] == [t[6] ...]  (cpp/parse_vcf.cpp:51-61).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_samples;   /* S: number of sample columns in the VCF (0 = sites only)             */
+    int32_t sc;          /* samples per chunk, 0 = dense                                        */
+    int32_t vc;          /* variants per chunk, 0 = dense                                       */
+    int32_t reserved;
+    uint64_t v_capacity; /* kept-variant capacity of the G buffer                               */
+} hhgt_layout;
+
+/* bytes needed for G under `lay` */
+uint64_t hhgt_layout_bytes(const hhgt_layout *lay);
+/* byte offset of (s, v, h=0) inside G */
+uint64_t hhgt_layout_offset(const hhgt_layout *lay, uint32_t s, uint64_t v);
+
+typedef struct {
+    uint64_t n_lines;          /* lines seen (header and blank included)                        */
+    uint64_t n_records;        /* data lines                                                    */
+    uint64_t n_kept;           /* records kept (region + isSNP)                                 */
+    uint64_t n_drop_region;    /* CHROM / range mismatch  (cpp/vcfpp.h:1424-1451)               */
+    uint64_t n_drop_filter;    /* !isSNP                  (cpp/vcfpp.h:990-1000)                */
+    uint64_t n_haploid_padded; /* calls with one allele: 2nd allele defined as -9               */
+    uint64_t n_malformed;      /* records the reference's parser would reject                   */
+    uint64_t n_general_lines;  /* kept lines that took the variable-width path                  */
+    uint64_t n_chrom_runs;     /* maximal runs of equal CHROM among data lines                  */
+} hhgt_encode_stats;
+
+/*
+ * Encode one device-resident block of VCF text (whole lines; header lines allowed and skipped).
+ *   d_text/nbytes : raw text, 16-byte aligned base, nbytes < 4 GiB.  Only [0, nbytes) is read.
+ *   region        : "" / NULL = all records; "chr22"; "chr22:beg-end" (1-based, inclusive)
+ *   v_base        : kept records are written at global kept index v_base + k
+ *   d_G           : chunk-tiled matrix (see above); d_start/d_stop/d_ref/d_alt: per kept record
+ *                   (0-based start, stop = start + len(REF) per cpp/vcfpp.h:1118-1127; REF/ALT are
+ *                   single bytes for every kept record by cpp/vcfpp.h:990-1000); any may be NULL.
+ *   stats         : host struct, filled on return.
+ * Synchronises `stream` before returning (counts are read back).  On HHGT_ERR_MALFORMED the
+ * outputs are undefined (the reference raises RuntimeError / asserts).
+ */
+int hhgt_encode_text(hhgt_ctx *ctx, const void *d_text, uint64_t nbytes, const char *region,
+                     const hhgt_layout *lay, uint64_t v_base, void *d_G, uint32_t *d_start,
+                     uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_stats *stats,
+                     void *stream);
+
+/* CHROM runs of the most recent hhgt_encode_text call (cpp/vcfpp.h:1076-1079 CHROM()):
+ * run r covers kept indices [first_kept[r], first_kept[r+1]) (batch-local, i.e. without v_base)
+ * and is named names[r*32 .. r*32+31] (NUL padded, truncated to 31 bytes). */
+int hhgt_encode_chrom_runs(hhgt_ctx *ctx, uint32_t max_runs, uint64_t *first_kept, char *names,
+                           uint32_t *n_runs);
+
+/* Zero the padding of G: variants [v_end, round_up(v_end, vc)) of the last chunk column and the
+ * sample rows [S, round_up(S, sc)) of chunk columns [vcol_begin, vcol_end). */
+int hhgt_pad_tail(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_t vcol_begin,
+                  uint64_t vcol_end, void *d_G, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Blosc2 chunk compress: byte-shuffle(typesize) + LZ4 block format, `blocksize`-byte blocks,
+ * split into `typesize` streams when 2 <= typesize <= 16 and blocksize/typesize >= 128
+ * (flag 0x10 "don't split" is set otherwise).  Replaces the HDF5 filter-32001 call at
+ * src/haplohyped/vcf_to_h5.py:134-135 (clevel 5, shuffle 1, LZ4-format codec).
+ *   d_src        : n_chunks contiguous chunks of chunk_nbytes bytes each
+ *   d_dst        : receives the framed chunks back to back; chunk i occupies
+ *                  [d_chunk_off[i], d_chunk_off[i+1])
+ *   d_chunk_off  : device array of n_chunks + 1 uint64
+ *   total_bytes  : host, optional; when non-NULL the call synchronises and returns the total
+ * Constraints: 1 <= typesize <= 255; blocksize % typesize == 0; 16 <= blocksize <= 65536 (clamped to the chunk size, as c-blosc does);
+ * chunk_nbytes < 2 GiB.
+ * ------------------------------------------------------------------------------------------- */
+uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize);
+int hhgt_compress_chunks(hhgt_ctx *ctx, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
+                         int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
+                         uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream);
+
+/* Inverse (read side, src/utils/h5_reader.py:37-41): decodes n_chunks framed chunks (either header
+ * format) into d_dst, chunk i at d_dst + i*chunk_nbytes.  typesize/blocksize are the dataset's
+ * (the headers are validated against them).  Sets *n_bad (host, optional, syncs) to
+ * the number of chunks that failed validation. */
+int hhgt_decompress_chunks(hhgt_ctx *ctx, const void *d_src, const uint64_t *d_chunk_off,
+                           uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize,
+                           void *d_dst, uint64_t *n_bad, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-stage device timing (HIP events on the launch stream).  Stages are indexed by HHGT_STAGE_*.
+ * hhgt_profile_read returns accumulated milliseconds and launch counts since the last reset.
+ * ------------------------------------------------------------------------------------------- */
+#define HHGT_STAGE_INDEX 0    /* newline index + compaction                                     */
+#define HHGT_STAGE_FIXED 1    /* fixed-column parse, filter, kept-record compaction              */
+#define HHGT_STAGE_ENCODE 2   /* GT tile encode (fixed-width path)                               */
+#define HHGT_STAGE_GENERAL 3  /* GT encode, variable-width lines                                 */
+#define HHGT_STAGE_LZ4 4      /* shuffle + LZ4 block encode                                      */
+#define HHGT_STAGE_FRAME 5    /* Blosc2 framing / compaction                                     */
+#define HHGT_STAGE_DECODE 6   /* chunk decode                                                    */
+#define HHGT_N_STAGES 8
+int hhgt_profile_enable(hhgt_ctx *ctx, int on);
+int hhgt_profile_reset(hhgt_ctx *ctx);
+int hhgt_profile_read(hhgt_ctx *ctx, double *ms /*[HHGT_N_STAGES]*/, uint64_t *launches /*[HHGT_N_STAGES]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,372 @@
+/*
+ * vcf_oracle.c — CPU ORACLE (test infrastructure only; see hhgt_oracle.h).
+ *
+ * Restates, in plain C, what the reference's native loader computes for every record:
+ *   record loop / filter / narrowing ........ /root/reference/cpp/parse_vcf.cpp:37-61
+ *   isSNP filter ............................ /root/reference/cpp/vcfpp.h:990-1000
+ *   allele decode ('.' -> -9, index else) .... /root/reference/cpp/vcfpp.h:546-588
+ *   Start/End/CHROM/REF/ALT .................. /root/reference/cpp/vcfpp.h:1076-1079,1118-1133,1142-1151
+ *   region / sample restriction ............. /root/reference/cpp/vcfpp.h:1355-1360,1424-1451,369-378
+ * The GT text -> allele-index rule itself lives in htslib's vcf_parse_format (htslib is an
+ * un-vendored, unpinned dependency: environment.yml:16; docs say >=1.15).  Its published
+ * algorithm, restated in parse_gt() below:
+ *     for (l = 0;; ++t) {
+ *        if (*t == '.')      { ++t; x[l++] = missing; }
+ *        else if (isdigit(*t)) x[l++] = strtol(t, &t, 10);
+ *        else break;
+ *        if (*t != '|' && *t != '/') break;
+ *     }
+ *     if (l == 0) x[l++] = missing;
+ * and the reference then keeps x[0], x[1] as int8 (parse_vcf.cpp:51-52).  A call with one allele
+ * (l == 1) trips assert(ploidy()==2) in the reference (parse_vcf.cpp:46) unless another sample of
+ * the same record is diploid; this build defines the second allele as -9 and counts it.
+ */
+#include "hhgt_oracle.h"
+#include <string.h>
+#include <stdlib.h>
+
+typedef struct {
+    const char *contig; /* not NUL terminated */
+    size_t contig_len;
+    int has_range;
+    int64_t beg, end; /* 1-based inclusive */
+} region_t;
+
+static void parse_region(const char *region, region_t *r)
+{
+    memset(r, 0, sizeof(*r));
+    if (!region || !*region) return;
+    const char *colon = strrchr(region, ':');
+    r->contig = region;
+    r->contig_len = strlen(region);
+    if (colon && colon[1] >= '0' && colon[1] <= '9') {
+        /* chr:beg-end or chr:beg */
+        char *p;
+        long long b = strtoll(colon + 1, &p, 10);
+        long long e = INT64_MAX;
+        while (*p == ',') p++;
+        if (*p == '-') {
+            if (p[1]) e = strtoll(p + 1, &p, 10);
+        } else if (*p == 0) {
+            e = INT64_MAX; /* samtools: "chr:beg" means beg..end of contig */
+        }
+        r->contig_len = (size_t)(colon - region);
+        r->has_range = 1;
+        r->beg = b;
+        r->end = e;
+    }
+}
+
+/* htslib vcf_parse_format GT rule (see file header).  Returns number of alleles parsed (>=1). */
+static int parse_gt(const uint8_t *t, const uint8_t *lim, int8_t out[2])
+{
+    int l = 0;
+    int vals[2] = {-9, -9};
+    for (;;) {
+        if (t < lim && *t == '.') {
+            ++t;
+            if (l < 2) vals[l] = -9; /* vcfpp.h:567-573 missing -> -9 */
+            l++;
+        } else if (t < lim && *t >= '0' && *t <= '9') {
+            long long v = 0;
+            while (t < lim && *t >= '0' && *t <= '9') {
+                v = v * 10 + (*t - '0');
+                if (v > 0x7fffffff) v &= 0x7fffffff;
+                ++t;
+            }
+            if (l < 2) vals[l] = (int)v; /* vcfpp.h:574 bcf_gt_allele */
+            l++;
+        } else
+            break;
+        if (t >= lim || (*t != '|' && *t != '/')) break;
+        ++t;
+    }
+    if (l == 0) {
+        vals[0] = -9;
+        l = 1;
+    }
+    out[0] = (int8_t)vals[0]; /* parse_vcf.cpp:51 static_cast<int8_t> */
+    out[1] = (int8_t)vals[1]; /* parse_vcf.cpp:52 */
+    return l;
+}
+
+typedef struct {
+    const uint8_t *f[10]; /* starts of fields 0..8, f[9] = start of first sample column */
+    const uint8_t *fe[9]; /* ends (exclusive) of fields 0..8 */
+    int nf;               /* number of fixed fields found (<=9) */
+} fixed_t;
+
+static void split_fixed(const uint8_t *s, const uint8_t *e, fixed_t *fx)
+{
+    const uint8_t *p = s;
+    fx->nf = 0;
+    fx->f[9] = e;
+    while (fx->nf < 9) {
+        const uint8_t *q = memchr(p, '\t', (size_t)(e - p));
+        fx->f[fx->nf] = p;
+        if (!q) {
+            fx->fe[fx->nf] = e;
+            fx->nf++;
+            return;
+        }
+        fx->fe[fx->nf] = q;
+        fx->nf++;
+        p = q + 1;
+    }
+    fx->f[9] = p;
+}
+
+/* cpp/vcfpp.h:990-1000: REF length <= 1, n_allele <= 2, ALT[0] in {A,C,G,T} exactly. */
+static int is_snp(const fixed_t *fx)
+{
+    size_t reflen = (size_t)(fx->fe[3] - fx->f[3]);
+    size_t altlen = (size_t)(fx->fe[4] - fx->f[4]);
+    if (reflen != 1) return 0;
+    if (altlen != 1) return 0; /* a comma => n_allele>2; longer => not "A|C|G|T"; "." => n_allele==1 */
+    uint8_t a = *fx->f[4];
+    return a == 'A' || a == 'C' || a == 'G' || a == 'T';
+}
+
+/* index of the GT key in FORMAT, -1 if absent */
+static int gt_key_index(const uint8_t *f, const uint8_t *fe)
+{
+    int idx = 0;
+    const uint8_t *p = f;
+    while (p <= fe) {
+        const uint8_t *q = memchr(p, ':', (size_t)(fe - p));
+        if (!q) q = fe;
+        if (q - p == 2 && p[0] == 'G' && p[1] == 'T') return idx;
+        idx++;
+        p = q + 1;
+    }
+    return -1;
+}
+
+typedef struct {
+    int keep;        /* 1 kept, 0 dropped, -1 malformed */
+    uint32_t start, stop;
+    uint8_t ref, alt;
+    int gt_idx;
+} rec_t;
+
+static int parse_record(const uint8_t *s, const uint8_t *e, const region_t *rg, int n_samples,
+                        fixed_t *fx, rec_t *rec, oracle_vcf_stats *st)
+{
+    split_fixed(s, e, fx);
+    rec->keep = 0;
+    if (fx->nf < 8 || (n_samples > 0 && fx->nf < 9)) {
+        st->n_malformed++;
+        rec->keep = -1;
+        return -1;
+    }
+    /* POS */
+    int64_t pos = 0;
+    const uint8_t *p = fx->f[1];
+    if (p == fx->fe[1]) {
+        st->n_malformed++;
+        rec->keep = -1;
+        return -1;
+    }
+    for (; p < fx->fe[1]; ++p) {
+        if (*p < '0' || *p > '9') {
+            st->n_malformed++;
+            rec->keep = -1;
+            return -1;
+        }
+        pos = pos * 10 + (*p - '0');
+    }
+    if (rg->contig) {
+        size_t cl = (size_t)(fx->fe[0] - fx->f[0]);
+        if (cl != rg->contig_len || memcmp(fx->f[0], rg->contig, cl) != 0 ||
+            (rg->has_range && (pos < rg->beg || pos > rg->end))) {
+            st->n_drop_region++;
+            return 0;
+        }
+    }
+    if (!is_snp(fx)) {
+        st->n_drop_filter++;
+        return 0;
+    }
+    rec->start = (uint32_t)(pos - 1);                               /* vcfpp.h:1118-1121 */
+    rec->stop = (uint32_t)(pos - 1 + (fx->fe[3] - fx->f[3]));       /* vcfpp.h:1124-1127 */
+    rec->ref = *fx->f[3];
+    rec->alt = *fx->f[4];
+    rec->gt_idx = 0;
+    if (n_samples > 0) {
+        rec->gt_idx = gt_key_index(fx->f[8], fx->fe[8]);
+        if (rec->gt_idx < 0) { /* vcfpp.h:550-552 "genotypes not present" */
+            st->n_malformed++;
+            rec->keep = -1;
+            return -1;
+        }
+    }
+    rec->keep = 1;
+    return 1;
+}
+
+/* returns pointer to the start of the k-th ':' sub-field of column [c, ce) (clipped) */
+static const uint8_t *subfield(const uint8_t *c, const uint8_t *ce, int k, const uint8_t **sub_end)
+{
+    const uint8_t *p = c;
+    while (k > 0) {
+        const uint8_t *q = memchr(p, ':', (size_t)(ce - p));
+        if (!q) { /* fewer sub-fields than FORMAT keys: trailing ones are missing */
+            *sub_end = ce;
+            return ce;
+        }
+        p = q + 1;
+        k--;
+    }
+    const uint8_t *q = memchr(p, ':', (size_t)(ce - p));
+    *sub_end = q ? q : ce;
+    return p;
+}
+
+static void line_bounds(const uint8_t *text, size_t n, size_t *pos, const uint8_t **s, const uint8_t **e)
+{
+    const uint8_t *b = text + *pos;
+    const uint8_t *nl = memchr(b, '\n', n - *pos);
+    const uint8_t *end = nl ? nl : text + n;
+    *pos = (size_t)(end - text) + (nl ? 1 : 0);
+    if (end > b && end[-1] == '\r') end--; /* bgzf_getline strips a trailing CR */
+    *s = b;
+    *e = end;
+}
+
+int64_t oracle_vcf_encode(const uint8_t *text, size_t n, const char *region, int n_samples,
+                          size_t cap, int8_t *G, uint32_t *start, uint32_t *stop,
+                          uint8_t *ref, uint8_t *alt, char *chrom, oracle_vcf_stats *st)
+{
+    oracle_vcf_stats local;
+    if (!st) st = &local;
+    memset(st, 0, sizeof(*st));
+    region_t rg;
+    parse_region(region, &rg);
+    size_t pos = 0;
+    int64_t v = 0;
+    while (pos < n) {
+        const uint8_t *s, *e;
+        line_bounds(text, n, &pos, &s, &e);
+        st->n_lines++;
+        if (e == s || *s == '#') continue;
+        st->n_records++;
+        fixed_t fx;
+        rec_t rec;
+        int r = parse_record(s, e, &rg, n_samples, &fx, &rec, st);
+        if (r < 0) return -2;
+        if (r == 0) continue;
+        if ((size_t)v >= cap) return -1;
+        const uint8_t *c = fx.f[9];
+        for (int smp = 0; smp < n_samples; ++smp) {
+            if (c > e) return -2; /* too few sample columns */
+            const uint8_t *ce = memchr(c, '\t', (size_t)(e - c));
+            if (!ce) ce = e;
+            const uint8_t *se;
+            const uint8_t *g = subfield(c, ce, rec.gt_idx, &se);
+            int8_t ph[2];
+            int l = parse_gt(g, se, ph);
+            if (l == 1) st->n_haploid_padded++;
+            G[((size_t)smp * cap + (size_t)v) * 2 + 0] = ph[0];
+            G[((size_t)smp * cap + (size_t)v) * 2 + 1] = ph[1];
+            c = ce + 1;
+        }
+        if (start) start[v] = rec.start;
+        if (stop) stop[v] = rec.stop;
+        if (ref) ref[v] = rec.ref;
+        if (alt) alt[v] = rec.alt;
+        if (chrom) {
+            size_t cl = (size_t)(fx.fe[0] - fx.f[0]);
+            if (cl > 31) cl = 31;
+            memset(chrom + v * 32, 0, 32);
+            memcpy(chrom + v * 32, fx.f[0], cl);
+        }
+        v++;
+    }
+    st->n_kept = v;
+    return v;
+}
+
+int64_t oracle_vcf_load_sample(const uint8_t *text, size_t n, const char *region, int n_samples,
+                               int sample_index, size_t cap, int8_t *phase, uint32_t *start,
+                               uint32_t *stop, uint8_t *ref, uint8_t *alt, oracle_vcf_stats *st)
+{
+    oracle_vcf_stats local;
+    if (!st) st = &local;
+    memset(st, 0, sizeof(*st));
+    if (sample_index < 0 || sample_index >= n_samples) return -2;
+    region_t rg;
+    parse_region(region, &rg);
+    size_t pos = 0;
+    int64_t v = 0;
+    while (pos < n) {
+        const uint8_t *s, *e;
+        line_bounds(text, n, &pos, &s, &e);
+        st->n_lines++;
+        if (e == s || *s == '#') continue;
+        st->n_records++;
+        fixed_t fx;
+        rec_t rec;
+        /* like vcf_parse1 (vcfpp.h:1471): every column of the line is tokenised, one is kept */
+        int r = parse_record(s, e, &rg, n_samples, &fx, &rec, st);
+        if (r < 0) return -2;
+        const uint8_t *c = fx.f[9];
+        const uint8_t *keep_c = NULL, *keep_ce = NULL;
+        for (int smp = 0; smp < n_samples; ++smp) {
+            if (c > e) return -2;
+            const uint8_t *ce = memchr(c, '\t', (size_t)(e - c));
+            if (!ce) ce = e;
+            if (smp == sample_index) {
+                keep_c = c;
+                keep_ce = ce;
+            }
+            c = ce + 1;
+        }
+        if (r == 0) continue;
+        if ((size_t)v >= cap) return -1;
+        const uint8_t *se;
+        const uint8_t *g = subfield(keep_c, keep_ce, rec.gt_idx, &se);
+        int8_t ph[2];
+        int l = parse_gt(g, se, ph);
+        if (l == 1) st->n_haploid_padded++;
+        phase[v * 2] = ph[0];
+        phase[v * 2 + 1] = ph[1];
+        if (start) start[v] = rec.start;
+        if (stop) stop[v] = rec.stop;
+        if (ref) ref[v] = rec.ref;
+        if (alt) alt[v] = rec.alt;
+        v++;
+    }
+    st->n_kept = v;
+    return v;
+}
+
+int oracle_vcf_header_samples(const uint8_t *text, size_t n, uint32_t *name_off, uint32_t *name_len,
+                              int max_names)
+{
+    size_t pos = 0;
+    while (pos < n) {
+        const uint8_t *s, *e;
+        line_bounds(text, n, &pos, &s, &e);
+        if (e == s) continue;
+        if (*s != '#') return -1;
+        if (e - s >= 6 && memcmp(s, "#CHROM", 6) == 0) {
+            int ntab = 0, ns = 0;
+            const uint8_t *p = s;
+            while (p < e) {
+                const uint8_t *q = memchr(p, '\t', (size_t)(e - p));
+                if (!q) q = e;
+                if (ntab >= 9) {
+                    if (name_off && ns < max_names) {
+                        name_off[ns] = (uint32_t)(p - text);
+                        name_len[ns] = (uint32_t)(q - p);
+                    }
+                    ns++;
+                }
+                ntab++;
+                p = q + 1;
+            }
+            return ns;
+        }
+    }
+    return -1;
+}
