@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — variants/s, encode + compress, on synthetic 1000G-style VCF text resident in HBM.
+
+One "step" = one pass of the hot path over the whole workload: for each of the 22 per-chromosome
+shards (3 000 000 variants x 2504 samples, BASELINE.json configs[2] — the configuration the metric
+is quoted on; ~30 GB of text, fits one MI355X):
+    hhgt_encode_text  (line index -> fixed columns/filter -> GT tiles)  ->  int8 G, chunk-tiled
+    hhgt_pad_tail
+    hhgt_compress_chunks (byte-shuffle + LZ4 -> Blosc2-framed chunks)
+Inputs (raw VCF text) are generated ON the GPU (csrc/synth.hip) before the timed region.
+
+Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
+time); shards are independent, there is no data-path collective.  Default "weak": every rank encodes
+its own 3 M-variant cohort (different seeds).  --scaling strong splits the 22 shards of ONE cohort
+over the ranks (longest-processing-time-first), as the north star's per-chromosome sharding does.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from haplohyped_varawareml_amd import device as dev  # noqa: E402
+from haplohyped_varawareml_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--variants", type=int, default=3_000_000)
+    ap.add_argument("--samples", type=int, default=2504)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
+    return ap.parse_args()
+
+
+def lpt_assign(sizes, n):
+    """longest-processing-time-first: shard indices per rank"""
+    loads = [0] * n
+    out = [[] for _ in range(n)]
+    for i in sorted(range(len(sizes)), key=lambda i: -sizes[i]):
+        r = loads.index(min(loads))
+        out[r].append(i)
+        loads[r] += sizes[i]
+    return [sorted(o) for o in out]
+
+
+class Shard:
+    pass
+
+
+def build_shards(ctx, args, rank, world):
+    sizes = synth.shard_sizes(args.variants)
+    if args.scaling == "strong":
+        mine = lpt_assign(sizes, world)[rank]
+        seed_off = 0
+    else:
+        mine = list(range(len(sizes)))
+        seed_off = 100_000 * rank
+    S = args.samples
+    shards = []
+    for ci in mine:
+        V = sizes[ci]
+        if V == 0:
+            continue
+        contig = f"chr{ci + 1}"
+        seed = 1000 + (ci + 1) + seed_off
+        tab = synth.variant_table(seed, V, S)
+        text, nbytes = ctx.synth_fixed(contig, tab, S, seed=seed)
+        sh = Shard()
+        sh.contig, sh.V, sh.text, sh.nbytes = contig, V, text, nbytes
+        sh.layout = dev.make_layout(S, V)
+        cap = sh.layout.v_capacity
+        d = ctx.device
+        sh.res = dev.EncodeResult(torch.zeros(dev.layout_bytes(sh.layout), dtype=torch.uint8, device=d), sh.layout,
+                                  torch.zeros(cap, dtype=torch.int32, device=d),
+                                  torch.zeros(cap, dtype=torch.int32, device=d),
+                                  torch.zeros(cap, dtype=torch.uint8, device=d),
+                                  torch.zeros(cap, dtype=torch.uint8, device=d), 0, {})
+        sh.chunk_nbytes = sh.layout.sc * sh.layout.vc * 2
+        sh.n_chunks = sh.res.G.numel() // sh.chunk_nbytes
+        sh.dst = torch.empty(sh.n_chunks * (sh.chunk_nbytes + 32), dtype=torch.uint8, device=d)
+        sh.off = torch.zeros(sh.n_chunks + 1, dtype=torch.int64, device=d)
+        sh.total = 0
+        shards.append(sh)
+    return shards
+
+
+def one_step(ctx, shards, S):
+    for sh in shards:
+        ctx.encode_text(sh.text, S, region=sh.contig, v_base=0, out=sh.res)
+        ctx.pad_tail(sh.res)
+        _, _, sh.total = ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=32768, fmt=dev.BLOSC2,
+                                      dst=sh.dst, chunk_off=sh.off, sync=False)
+
+
+def cpu_baseline(ctx, shards, S, target_s):
+    """oracle (CPU restatement of the reference path, matrix-shaped, 1 thread) on a bounded sample of
+    the same workload: the first n lines of the largest shard."""
+    from oracle import oracle
+    sh = max(shards, key=lambda s: s.V)
+    bytes_per_line = sh.nbytes / max(sh.V, 1)
+
+    def run(n_lines):
+        nb = min(sh.nbytes, int(n_lines * bytes_per_line) + 65536)
+        host = sh.text[:nb].cpu().numpy()
+        last_nl = int(np.flatnonzero(host == 10)[-1]) + 1
+        host = host[:last_nl]
+        t0 = time.perf_counter()
+        o = oracle.vcf_encode(host, S, region=sh.contig, cap=n_lines + 64)
+        t1 = time.perf_counter()
+        G = o["G"]                       # [S, V, 2]; one sample row per Blosc block, 64 rows per chunk
+        V = G.shape[1]
+        cbytes = 0
+        blk = V * 2
+        for s0 in range(0, S, 64):
+            raw = np.ascontiguousarray(G[s0:s0 + 64]).reshape(-1).view(np.uint8)
+            cbytes += oracle.blosc_compress(raw, 2, min(blk, 65536 - (65536 % 2))).size
+        t2 = time.perf_counter()
+        return V, t1 - t0, t2 - t1, cbytes, G.size
+
+    V0, te, tc, _, _ = run(4000)
+    per_line = (te + tc) / max(V0, 1)
+    n = int(min(sh.V, max(4000, target_s / max(per_line, 1e-9))))
+    V, te, tc, cb, raw = run(n)
+    return {
+        "value": V / (te + tc), "unit": "variants/s", "cores": 1, "kind": "port",
+        "sample": f"first {V} variants of {sh.contig} ({S} samples): oracle encode {te:.2f}s + shuffle/LZ4/Blosc2 {tc:.2f}s, ratio {raw / max(cb, 1):.2f}",
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    ctx = dev.Context(local_rank)
+    S = args.samples
+    shards = build_shards(ctx, args, rank, world)
+    my_variants = sum(sh.V for sh in shards)
+    text_bytes = sum(sh.nbytes for sh in shards)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(ctx, shards, S)
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(ctx, shards, S)
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = ctx.profile_read()
+    ctx.profile(False)
+
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tv = torch.tensor([float(my_variants)], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+    dt_max, total_variants = float(tt.item()), float(tv.item())
+
+    # sizes for the roofline (algorithmic bytes), this rank
+    comp_bytes = sum(int(sh.off[-1].item()) for sh in shards)
+    g_bytes = sum(sh.res.stats["n_kept"] * 2 * S for sh in shards)          # V' * 2S
+    alg = {
+        "index": text_bytes, "fixed": 0, "encode": sum(sh.V * 4 * S for sh in shards) + g_bytes,
+        "lz4": g_bytes + comp_bytes, "frame": 2 * comp_bytes,
+    }
+    # dominant kernel stage = largest share of device time
+    dom = max((k for k in stages if k in alg), key=lambda k: stages[k]["ms"])
+    dom_ms_per_launch = stages[dom]["ms"] / max(stages[dom]["launches"], 1)
+    dom_bytes_per_launch = alg[dom] / max(len(shards), 1)                     # one launch per shard per step
+    achieved = dom_bytes_per_launch / (dom_ms_per_launch * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_blocks", "encode": "k_encode_tiles", "index": "k_index_newlines",
+                                       "frame": "k_frame_write"}.get(dom, dom),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "bytes_per_launch": dom_bytes_per_launch, "ms_per_launch": dom_ms_per_launch}
+
+    out = {
+        "metric": "variants/sec encode+compress, 3M-variant x 2.5k-sample VCF",
+        "value": total_variants * args.steps / dt_max, "unit": "variants/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"1000G-style {args.variants} variants x {S} samples, 22 per-chromosome shards "
+                               f"(BASELINE configs[2]), biallelic phased GT-only text resident in HBM",
+                   "variants_per_gpu": my_variants, "samples": S, "text_bytes_per_gpu": text_bytes,
+                   "chunk": "64 samples x 16384 variants x 2 (2 MiB), block 32 KiB, typesize 2, LZ4, Blosc2 frame",
+                   "compression_ratio": g_bytes / max(comp_bytes, 1),
+                   "parallelism": f"per-chromosome shards x{world}, no collective"},
+        "roofline": roof,
+        "stages_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ctx, shards, S, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

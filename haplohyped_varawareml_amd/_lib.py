@@ -43,6 +43,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: it must be in the process BEFORE libhhgt.so pulls in
+    # libamdhip64, or the two runtimes disagree about the visible devices
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing. Build it with `python -m haplohyped_varawareml_amd.build` "

@@ -230,15 +230,15 @@ int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_
     // split launch is staged across the whole staging area
     uint32_t cstride = sstride;
     const size_t lds = (size_t)nwaves * sstride + 16u + (size_t)nwaves * cstride + 16u;
-    if (lds > 160 * 1024) {
+    if (lds > 160 * 1024 - 64) {
         hhgt_set_error("decode: block of %d bytes x typesize %d does not fit LDS", blocksize, typesize);
         return HHGT_ERR_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in
+    if (lds > attr_lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_blocks),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
     }
     const uint64_t grid = n_chunks * nblocks;
     if (grid > 0x7fffffffull) {

@@ -215,15 +215,15 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     // keep >= 4 workgroups per CU resident when the block allows it (160 KiB LDS per CU)
     while (hashlog > 10 && data_bytes + ((size_t)nwaves << (hashlog + 1)) > 40960) --hashlog;
     const size_t lds = data_bytes + ((size_t)nwaves << (hashlog + 1));
-    if (lds > 160 * 1024) {
+    if (lds > 160 * 1024 - 64) {
         hhgt_set_error("lz4: block of %d bytes x typesize %d does not fit LDS", blocksize, typesize);
         return HHGT_ERR_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in
+    if (lds > attr_lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lz4_blocks),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
     }
     const uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
