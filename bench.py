@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--variants", type=int, default=3_000_000)
     ap.add_argument("--samples", type=int, default=2504)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--vc", type=int, default=dev.DEFAULT_VC, help="variants per chunk; Blosc2 block = one sample row = 2*vc bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
     return ap.parse_args()
@@ -80,7 +81,7 @@ def build_shards(ctx, args, rank, world):
         text, nbytes = ctx.synth_fixed(contig, tab, S, seed=seed)
         sh = Shard()
         sh.contig, sh.V, sh.text, sh.nbytes = contig, V, text, nbytes
-        sh.layout = dev.make_layout(S, V)
+        sh.layout = dev.make_layout(S, V, vc=args.vc)
         cap = sh.layout.v_capacity
         d = ctx.device
         sh.res = dev.EncodeResult(torch.zeros(dev.layout_bytes(sh.layout), dtype=torch.uint8, device=d), sh.layout,
@@ -97,11 +98,11 @@ def build_shards(ctx, args, rank, world):
     return shards
 
 
-def one_step(ctx, shards, S):
+def one_step(ctx, shards, S, blocksize):
     for sh in shards:
         ctx.encode_text(sh.text, S, region=sh.contig, v_base=0, out=sh.res)
         ctx.pad_tail(sh.res)
-        _, _, sh.total = ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=32768, fmt=dev.BLOSC2,
+        _, _, sh.total = ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2,
                                       dst=sh.dst, chunk_off=sh.off, sync=False)
 
 
@@ -165,13 +166,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(ctx, shards, S)
+        one_step(ctx, shards, S, 2 * args.vc)
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(ctx, shards, S)
+        one_step(ctx, shards, S, 2 * args.vc)
     barrier()
     dt = time.perf_counter() - t0
     stages = ctx.profile_read()
@@ -218,7 +219,7 @@ def main():
         "config": {"workload": f"1000G-style {args.variants} variants x {S} samples, 22 per-chromosome shards "
                                f"(BASELINE configs[2]), biallelic phased GT-only text resident in HBM",
                    "variants_per_gpu": my_variants, "samples": S, "text_bytes_per_gpu": text_bytes,
-                   "chunk": "64 samples x 16384 variants x 2 (2 MiB), block 32 KiB, typesize 2, LZ4, Blosc2 frame",
+                   "chunk": f"64 samples x {args.vc} variants x 2, block = one sample row = {2 * args.vc} B, typesize 2, LZ4, Blosc2 frame",
                    "compression_ratio": g_bytes / max(comp_bytes, 1),
                    "parallelism": f"per-chromosome shards x{world}, no collective"},
         "roofline": roof,

@@ -9,11 +9,13 @@ import torch
 from . import _lib
 from ._lib import BLOSC1, BLOSC2, EncodeStats, HhgtError, Layout, check
 
-# default on-disk geometry: one HDF5 chunk = 64 samples x 16384 variants x 2 haplotypes (2 MiB);
-# one Blosc2 block = one sample row of the chunk (32 KiB); typesize 2 = one diploid call
+# default on-disk geometry: one HDF5 chunk = 64 samples x 8192 variants x 2 haplotypes (1 MiB);
+# one Blosc2 block = one sample row of the chunk (16 KiB -> two 8 KiB byte planes, which lets 16
+# LZ4 waves stay resident per CU); typesize 2 = one diploid call
 DEFAULT_SC = 64
-DEFAULT_VC = 16384
+DEFAULT_VC = 8192
 DEFAULT_TYPESIZE = 2
+DEFAULT_BLOCKSIZE = DEFAULT_VC * 2
 
 
 def make_layout(n_samples, v_capacity, sc=DEFAULT_SC, vc=DEFAULT_VC):
@@ -145,7 +147,7 @@ class Context:
         assert src.numel() % chunk_nbytes == 0
         n_chunks = src.numel() // chunk_nbytes
         if blocksize is None:
-            blocksize = min(chunk_nbytes, 32768)
+            blocksize = min(chunk_nbytes, DEFAULT_BLOCKSIZE)
             blocksize -= blocksize % typesize
         with torch.cuda.device(self.device):
             cap = int(self.lib.hhgt_compress_bound(n_chunks, chunk_nbytes, typesize, blocksize))
@@ -165,7 +167,7 @@ class Context:
                    dst=None):
         """-> (dst uint8 tensor [n_chunks*chunk_nbytes], n_bad)"""
         if blocksize is None:
-            blocksize = min(int(chunk_nbytes), 32768)
+            blocksize = min(int(chunk_nbytes), DEFAULT_BLOCKSIZE)
             blocksize -= blocksize % typesize
         with torch.cuda.device(self.device):
             if dst is None:

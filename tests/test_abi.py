@@ -49,11 +49,13 @@ def test_no_device_fails_loudly():
 def test_layout_helpers_are_host_side():
     from haplohyped_varawareml_amd import _lib, device
     L = _lib.load()
-    lay = device.make_layout(2504, 100000)           # 64 x 16384 chunks
+    lay = device.make_layout(2504, 100000, sc=64, vc=16384)
     assert lay.v_capacity == 7 * 16384
     assert device.layout_bytes(lay) == 40 * 64 * 7 * 16384 * 2
     off = L.hhgt_layout_offset(ctypes.byref(lay), 65, 16385)
     assert off == (((1 * 40 + 1) * 64 + 1) * 16384 + 1) * 2
+    d = device.make_layout(2504, 100000)             # default geometry: 64 x 8192 chunks
+    assert d.vc == 8192 and d.v_capacity == 13 * 8192
     dense = device.make_layout(3, 1000, sc=0, vc=0)
     assert dense.v_capacity == 1024 and L.hhgt_layout_offset(ctypes.byref(dense), 2, 5) == (2 * 1024 + 5) * 2
 
