@@ -1,0 +1,175 @@
+"""File -> device pipeline: host inflate (C++ reader threads) -> pinned ring -> hipMemcpyAsync on a copy
+stream (double-buffered against the kernels) -> hhgt_encode_text appends into a staging window of chunk
+columns -> completed columns go through hhgt_compress_chunks and leave the device framed.
+
+Replaces the body of VCFtoHDF5Converter.genotype_vcf_to_hdf5
+(/root/reference/src/haplohyped/vcf_to_h5.py:79-140): one pass per FILE for all samples instead of one
+pass per (donor, chromosome)."""
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import device as dev
+from .reader import VcfReader, parse_header
+
+
+@dataclass
+class FileStats:
+    n_samples: int = 0
+    n_lines: int = 0
+    n_records: int = 0
+    n_kept: int = 0
+    n_drop_region: int = 0
+    n_drop_filter: int = 0
+    n_haploid_padded: int = 0
+    n_general_lines: int = 0
+    text_bytes: int = 0
+    file_bytes: int = 0
+    raw_bytes: int = 0
+    compressed_bytes: int = 0
+    seconds: float = 0.0
+    is_bgzf: bool = False
+    samples: list = field(default_factory=list)
+    chrom_runs: list = field(default_factory=list)
+
+
+def _accumulate(fs, st):
+    for k in ("n_lines", "n_records", "n_drop_region", "n_drop_filter", "n_haploid_padded", "n_general_lines"):
+        setattr(fs, k, getattr(fs, k) + st[k])
+
+
+def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=64 << 20, n_threads=0,
+                sites_only=False, on_columns=None, on_variants=None, on_header=None, compress=True, fmt=dev.BLOSC2):
+    """Streams one VCF through the device path.
+    on_header(samples)                         once
+    on_variants(start, ref, alt)               numpy arrays for each text block's kept records
+    on_columns(G_cols, n_cols, framed)         for every batch of completed chunk columns:
+        G_cols: uint8 CUDA tensor [n_cols * column_bytes] (valid during the call),
+        framed: (host bytes, offsets uint64[n_chunks+1]) when compress=True else None
+    -> FileStats"""
+    t_start = time.perf_counter()
+    fs = FileStats()
+    d = ctx.device
+    with VcfReader(path, block_bytes=block_bytes, n_threads=n_threads) as rd:
+        fs.is_bgzf = rd.is_bgzf
+        blk = rd.next_block()
+        if blk is None:
+            raise dev.HhgtError(-4, f"{path}: empty file (no VCF header)")
+        names, _ = parse_header(blk)
+        fs.samples = names
+        S = 0 if sites_only else len(names)
+        fs.n_samples = S
+        if on_header:
+            on_header(names)
+        max_lines = block_bytes // (2 * S + 16) + 2
+        W = -(-max_lines // vc) + 1
+        lay = dev.make_layout(S, W * vc, sc=sc, vc=vc)
+        col_bytes = dev.layout_bytes(lay) // W if S else 0
+        chunk_nbytes = sc * vc * 2
+        cap = lay.v_capacity
+
+        def new_stage():
+            return dev.EncodeResult(torch.zeros(max(dev.layout_bytes(lay), 16), dtype=torch.uint8, device=d), lay,
+                                    torch.zeros(cap, dtype=torch.int32, device=d),
+                                    torch.zeros(cap, dtype=torch.int32, device=d),
+                                    torch.zeros(cap, dtype=torch.uint8, device=d),
+                                    torch.zeros(cap, dtype=torch.uint8, device=d), 0, {})
+
+        stage, spare = new_stage(), new_stage()
+        dbuf = [torch.empty(block_bytes + 64, dtype=torch.uint8, device=d) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=d)
+        main = torch.cuda.current_stream(d)
+        rd.copy_async(blk, dbuf[0].data_ptr(), copy_stream.cuda_stream)
+        copy_stream.synchronize()
+        cur_n, i, fill, v_global = blk.size, 0, 0, 0
+        last_run = None
+        while cur_n:
+            nxt = rd.next_block()
+            if nxt is not None:
+                rd.copy_async(nxt, dbuf[1 - i].data_ptr(), copy_stream.cuda_stream)   # overlaps the kernels below
+            ctx.encode_text(dbuf[i][:cur_n], S, region=region, v_base=fill, out=stage)
+            st = stage.stats
+            _accumulate(fs, st)
+            fs.text_bytes += cur_n
+            k = st["n_kept"]
+            for first, name in stage.chrom_runs:
+                if name != last_run:
+                    fs.chrom_runs.append((v_global + first, name))
+                    last_run = name
+            if on_variants and k:
+                on_variants(stage.start[fill:fill + k].cpu().numpy().view(np.uint32),
+                            stage.ref[fill:fill + k].cpu().numpy(), stage.alt[fill:fill + k].cpu().numpy())
+            total = fill + k
+            done = total // vc
+            if done and S:
+                _emit(ctx, stage, done, col_bytes, chunk_nbytes, on_columns, compress, fmt, fs)
+            rem = total - done * vc
+            if done:
+                # carry the partial column into column 0 of the other staging window
+                if rem and S:
+                    spare.G[:col_bytes].copy_(stage.G[done * col_bytes:(done + 1) * col_bytes])
+                stage, spare = spare, stage
+            fill = rem
+            v_global += k
+            copy_stream.synchronize()   # the next block sits in HBM before its pinned source is recycled
+            main.synchronize()
+            cur_n = nxt.size if nxt is not None else 0
+            i ^= 1
+        if fill and S:
+            stage.n_kept = fill
+            ctx.pad_tail(stage, v_end=fill, vcol_begin=0, vcol_end=1)
+            _emit(ctx, stage, 1, col_bytes, chunk_nbytes, on_columns, compress, fmt, fs)
+        elif S:
+            pass
+        fs.n_kept = v_global
+        fs.file_bytes = rd.stats()["file_bytes"]
+    fs.seconds = time.perf_counter() - t_start
+    return fs
+
+
+def _emit(ctx, stage, n_cols, col_bytes, chunk_nbytes, on_columns, compress, fmt, fs):
+    lay = stage.layout
+    # sample-padding rows of the completed columns must be zero before they are framed
+    if lay.sc and lay.n_samples % lay.sc:
+        ctx.pad_tail(stage, v_end=n_cols * lay.vc, vcol_begin=0, vcol_end=n_cols)
+    cols = stage.G[: n_cols * col_bytes]
+    framed = None
+    fs.raw_bytes += cols.numel()
+    if compress:
+        dst, off, total = ctx.compress(cols, chunk_nbytes, typesize=dev.DEFAULT_TYPESIZE, blocksize=lay.vc * 2, fmt=fmt)
+        framed = (dst[:total].cpu().numpy(), off.cpu().numpy().astype(np.uint64))
+        fs.compressed_bytes += total
+    if on_columns:
+        on_columns(cols, n_cols, framed)
+
+
+def encode_file_resident(ctx, path, region="", sites_only=False, block_bytes=64 << 20, n_threads=0):
+    """Whole file -> dense int8 G [S, V, 2] on the device plus tables on the host (used by the
+    parse_vcf facade and by tests; large cohorts should stream with stream_file instead)."""
+    cols, tabs = [], []
+
+    def on_columns(G_cols, n_cols, framed):
+        cols.append(G_cols.clone())
+
+    def on_variants(start, ref, alt):
+        tabs.append((start.copy(), ref.copy(), alt.copy()))
+
+    vc = 1024
+    fs = stream_file(ctx, path, region=region, sc=0, vc=vc, block_bytes=block_bytes, n_threads=n_threads,
+                     sites_only=sites_only, on_columns=on_columns, on_variants=on_variants, compress=False)
+    S, V = fs.n_samples, fs.n_kept
+    if S and cols:
+        # dense layout per column: [1][1][S][vc][2] -> concatenate columns along the variant axis
+        parts = []
+        for c in cols:
+            n = c.numel() // (S * vc * 2)
+            parts.append(c.view(torch.int8).view(n, S, vc, 2).permute(1, 0, 2, 3).reshape(S, n * vc, 2))
+        G = torch.cat(parts, dim=1)[:, :V].contiguous()
+    else:
+        G = torch.zeros((S, V, 2), dtype=torch.int8, device=ctx.device)
+    start = np.concatenate([t[0] for t in tabs]) if tabs else np.zeros(0, np.uint32)
+    ref = np.concatenate([t[1] for t in tabs]) if tabs else np.zeros(0, np.uint8)
+    alt = np.concatenate([t[2] for t in tabs]) if tabs else np.zeros(0, np.uint8)
+    return G, start, ref, alt, fs

@@ -1,0 +1,46 @@
+/*
+ * hhgt_reader.h — host side of the path: VCF text from disk into pinned memory, ready for the device.
+ *
+ * Replaces what the reference gets from htslib through vcfpp (NOT in the reference tree; unpinned
+ * system dependency, environment.yml:16):
+ *   hts_open / bcf_hdr_read ............ /root/reference/cpp/vcfpp.h:1378-1385
+ *   tbx_itr_next -> bgzf_getline ....... /root/reference/cpp/vcfpp.h:1468   (BGZF inflate + line framing)
+ * As BASELINE.json's north star prescribes, decompression stays on the host cores: BGZF blocks are
+ * inflated in parallel by worker threads, plain gzip (like the reference's fixture
+ * tests/data/chr22.filtered.vcf.gz) by one streaming inflater; the text lands in a ring of PINNED
+ * buffers cut at line boundaries, from which hhgt_reader_copy_async issues hipMemcpyAsync on the
+ * caller's stream (double buffering: the copy of block k+1 overlaps the kernels of block k).
+ * No tabix index is needed: region selection happens on the device (hhgt_encode_text's `region`).
+ */
+#ifndef HHGT_READER_H
+#define HHGT_READER_H
+#include "hhgt.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hhgt_reader hhgt_reader;
+
+/* path: .vcf, .vcf.gz (gzip or BGZF).  block_bytes: size of each pinned block (>= 1 MiB; lines longer
+ * than a block are an error).  n_threads: BGZF inflate workers (0 = hardware concurrency, max 64).
+ * n_blocks: ring depth (>= 2; 0 = 3). */
+int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_threads, int n_blocks, hhgt_reader **out);
+void hhgt_reader_close(hhgt_reader *r);
+
+/* 1 if the file is BGZF (block-parallel inflate), 0 for plain gzip / uncompressed */
+int hhgt_reader_is_bgzf(const hhgt_reader *r);
+
+/* Next block of whole lines.  *host_ptr stays valid until the next hhgt_reader_next/close call.
+ * *nbytes == 0 at end of file.  The final line is delivered even without a trailing newline. */
+int hhgt_reader_next(hhgt_reader *r, const void **host_ptr, uint64_t *nbytes);
+
+/* hipMemcpyAsync(d_dst, host_ptr, nbytes, HostToDevice, stream) from the reader's pinned block */
+int hhgt_reader_copy_async(hhgt_reader *r, const void *host_ptr, uint64_t nbytes, void *d_dst, void *stream);
+
+/* totals so far: compressed bytes consumed from disk, text bytes produced */
+int hhgt_reader_stats(const hhgt_reader *r, uint64_t *file_bytes, uint64_t *text_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""-m gpu: files -> reader -> device pipeline -> store, through the reference's own surfaces
+(parse_vcf.VCFLoader, VCFtoHDF5Converter, VCFH5Reader), against the oracle and the golden vectors."""
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from haplohyped_varawareml_amd import synth
+from haplohyped_varawareml_amd.reader import write_bgzf
+
+pytestmark = pytest.mark.gpu
+
+
+def test_facade_fixture_tuples(golden_dir, fixture_text, fixture_golden, capsys):
+    import parse_vcf
+    path = os.path.join(golden_dir, "chr22.filtered.vcf.gz")
+    G = np.load(os.path.join(golden_dir, "fixture_G.npy"))
+    for s, name in enumerate(fixture_golden["samples"]):
+        rows = parse_vcf.load_vcf(path, name, "chr22")           # the spelling of vcf_to_h5.py:101
+        assert len(rows) == 1000 and isinstance(rows[0], tuple) and len(rows[0]) == 7
+        assert [r[5] for r in rows] == G[s, :, 0].tolist() and [r[6] for r in rows] == G[s, :, 1].tolist()
+        assert all(type(v) is t for v, t in zip(rows[0], (str, int, int, str, str, int, int)))
+    assert list(rows[0][:5]) == fixture_golden["first_tuple_sample0"][:5]
+    assert f"Loaded 1000 SNPs for sample {name} and chromosome chr22" in capsys.readouterr().out
+    sites = parse_vcf.VCFLoader().load_vcf_without_sample(path, "chr22")
+    assert len(sites) == 1000 and sites[0] == tuple(fixture_golden["first_tuple_sample0"][:5])
+    assert parse_vcf.VCFLoader().load_vcf(path, name) == rows                      # chrom defaults to ""
+    with pytest.raises(RuntimeError, match="sample are not in the VCF"):
+        parse_vcf.load_vcf(path, "nobody", "chr22")
+    assert parse_vcf.load_vcf(path, name, "chr21") == []
+
+
+@pytest.mark.parametrize("kind", ["gzip", "bgzf"])
+def test_stream_file_small_blocks(ctx, tmp_path, kind):
+    """many small text blocks: double-buffered H2D, appends across blocks and chunk columns"""
+    from haplohyped_varawareml_amd.pipeline import encode_file_resident
+    S, V = 500, 6000
+    tab = synth.variant_table(8, V, S)
+    text, _ = synth.render_fixed_numpy("chr8", tab, S, seed=8)
+    p = str(tmp_path / "chr8.vcf.gz")
+    if kind == "gzip":
+        with gzip.open(p, "wb", compresslevel=1) as f:
+            f.write(text)
+    else:
+        write_bgzf(p, text, level=1)
+    G, start, ref, alt, fs = encode_file_resident(ctx, p, region="chr8", block_bytes=1 << 20)
+    o = oracle.vcf_encode(text, S, region="chr8")
+    assert fs.n_kept == V and fs.is_bgzf == (kind == "bgzf") and fs.text_bytes == len(text)
+    assert np.array_equal(G.cpu().numpy(), o["G"])
+    assert np.array_equal(start, o["start"]) and np.array_equal(ref, o["ref"]) and np.array_equal(alt, o["alt"])
+    assert fs.chrom_runs == [(0, "chr8")]
+
+
+def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
+    """vcf_to_h5 on the reference's own test inputs (tests/data/README.md 'Test VCF to HDF5 Conversion')
+    plus a synthetic mixed chr4; read back through VCFH5Reader.fetch_genotypes"""
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    from haplohyped_varawareml_amd.h5_reader import VCFH5Reader
+    from haplohyped_varawareml_amd.store import SNP_DTYPE
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr22.filtered.vcf.gz"), vcf_dir / "chr22.filtered.vcf.gz")
+    names = fixture_golden["samples"]
+    mixed = synth.render_mixed("chr4", 900, 3, seed=4, names=names)
+    write_bgzf(str(vcf_dir / "chr4.filtered.vcf.gz"), mixed)
+    conv = VCFtoHDF5Converter("test_cohort", str(vcf_dir), str(tmp_path / "out"),
+                              os.path.join(golden_dir, "ipscs_samples_test.txt"), cores=2, cxx_threads=1)
+    store = conv.run()
+    assert store == str(tmp_path / "out" / "test_cohort.hhgt") and not os.path.exists(conv.tmp_dir)
+    rd = VCFH5Reader(store, ctx=ctx)
+    assert sorted(rd.store.groups()) == ["chr_22", "chr_4"]
+    G22 = np.load(os.path.join(golden_dir, "fixture_G.npy"))
+    o4 = oracle.vcf_encode(mixed, 3, region="chr4")
+    for s, donor in enumerate(conv.donor_ids):
+        rec = rd.fetch_genotypes(donor, 22)
+        assert rec.dtype == SNP_DTYPE and rec.dtype.itemsize == 35 and len(rec) == 1000
+        assert np.array_equal(rec["phase1"], G22[s, :, 0]) and np.array_equal(rec["phase2"], G22[s, :, 1])
+        assert rec["chrom"][0] == b"chr22" and int(rec["start"][0]) == 10012121 and int(rec["stop"][0]) == 10012122
+        r4 = rd.fetch_genotypes(donor, 4)
+        assert len(r4) == o4["n_kept"]
+        assert np.array_equal(r4["phase1"], o4["G"][s, :, 0]) and np.array_equal(r4["phase2"], o4["G"][s, :, 1])
+        assert np.array_equal(r4["start"], o4["start"]) and b"".join(r4["ref"].tolist()) == bytes(o4["ref"])
+    with pytest.raises(KeyError):
+        rd.fetch_genotypes(conv.donor_ids[0], 5)
+    # every stored chunk is a Blosc2 frame the oracle decodes to the chunk-tiled matrix bytes
+    off = np.load(os.path.join(store, "chr_22", "offsets.npy"))
+    raw = np.fromfile(os.path.join(store, "chr_22", "chunks.bin"), dtype=np.uint8)
+    back = oracle.blosc_decompress(raw[off[0]:off[1]])
+    assert back.size == 64 * 8192 * 2
+    assert np.array_equal(back.view(np.int8).reshape(64, 8192, 2)[:3, :1000], G22)
+    assert not back.view(np.int8).reshape(64, 8192, 2)[3:].any()

@@ -1,0 +1,85 @@
+"""CPU: the host reader (C++: mmap + zlib, BGZF blocks inflated in parallel) delivers exactly the
+file's text, cut at line boundaries, for plain / gzip / multi-member gzip / BGZF inputs."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from haplohyped_varawareml_amd import synth
+from haplohyped_varawareml_amd.reader import VcfReader, parse_header, write_bgzf
+
+
+def collect(path, **kw):
+    out = []
+    with VcfReader(path, **kw) as r:
+        bg = r.is_bgzf
+        for b in r:
+            assert b.size > 0
+            out.append(bytes(b))
+    return out, bg
+
+
+@pytest.fixture(scope="module")
+def text():
+    tab = synth.variant_table(3, 3000, 200)
+    t, _ = synth.render_fixed_numpy("chr3", tab, 200, seed=3)
+    return t      # ~2.5 MB
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "gzip2", "bgzf"])
+@pytest.mark.parametrize("block", [1 << 20, 8 << 20])
+def test_roundtrip(tmp_path, text, kind, block):
+    p = str(tmp_path / f"x.{kind}")
+    if kind == "plain":
+        open(p, "wb").write(text)
+    elif kind == "gzip":
+        with gzip.open(p, "wb", compresslevel=1) as f:
+            f.write(text)
+    elif kind == "gzip2":   # concatenated members (bgzip-less tools do this)
+        cut = len(text) // 3
+        with open(p, "wb") as f:
+            f.write(gzip.compress(text[:cut], 1))
+            f.write(gzip.compress(text[cut:], 1))
+    else:
+        write_bgzf(p, text)
+    blocks, bg = collect(p, block_bytes=block, n_threads=4)
+    assert bg == (kind == "bgzf")
+    assert b"".join(blocks) == text
+    assert all(b.endswith(b"\n") for b in blocks)
+    if block == 1 << 20:
+        assert len(blocks) >= 2
+
+
+def test_no_trailing_newline_and_empty(tmp_path):
+    p = str(tmp_path / "a.vcf")
+    open(p, "wb").write(b"#x\nline1\nline2")
+    blocks, _ = collect(p)
+    assert b"".join(blocks) == b"#x\nline1\nline2"
+    open(p, "wb").write(b"")
+    assert collect(p)[0] == []
+
+
+def test_reference_fixture_header(golden_dir, fixture_golden):
+    with VcfReader(os.path.join(golden_dir, "chr22.filtered.vcf.gz")) as r:
+        assert not r.is_bgzf           # the reference's fixture is plain gzip
+        b = r.next_block()
+        names, hdr = parse_header(b)
+        assert names == fixture_golden["samples"]
+        assert bytes(b[hdr:hdr + 5]) == b"chr22" and b.size == fixture_golden["text_bytes"]
+        assert r.next_block() is None
+        assert r.stats()["text_bytes"] == fixture_golden["text_bytes"]
+
+
+def test_errors(tmp_path):
+    from haplohyped_varawareml_amd._lib import HhgtError
+    with pytest.raises(HhgtError):
+        VcfReader(str(tmp_path / "missing.vcf.gz"))
+    p = str(tmp_path / "trunc.vcf.gz")
+    open(p, "wb").write(gzip.compress(b"abc\n" * 100000)[:-200])
+    with pytest.raises(HhgtError, match="truncated|inflate"):
+        collect(p)
+    q = str(tmp_path / "long.vcf")
+    open(q, "wb").write(b"x" * (3 << 20))
+    with pytest.raises(HhgtError, match="longer than"):
+        collect(q, block_bytes=1 << 20)
