@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 from haplohyped_varawareml_amd import device as dev  # noqa: E402
 from haplohyped_varawareml_amd import synth  # noqa: E402
+from haplohyped_varawareml_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
@@ -46,29 +47,13 @@ def parse_args():
     return ap.parse_args()
 
 
-def lpt_assign(sizes, n):
-    """longest-processing-time-first: shard indices per rank"""
-    loads = [0] * n
-    out = [[] for _ in range(n)]
-    for i in sorted(range(len(sizes)), key=lambda i: -sizes[i]):
-        r = loads.index(min(loads))
-        out[r].append(i)
-        loads[r] += sizes[i]
-    return [sorted(o) for o in out]
-
-
 class Shard:
     pass
 
 
 def build_shards(ctx, args, rank, world):
     sizes = synth.shard_sizes(args.variants)
-    if args.scaling == "strong":
-        mine = lpt_assign(sizes, world)[rank]
-        seed_off = 0
-    else:
-        mine = list(range(len(sizes)))
-        seed_off = 100_000 * rank
+    mine, seed_off = sharding.plan(sizes, rank, world, args.scaling)
     S = args.samples
     shards = []
     for ci in mine:
@@ -178,12 +163,7 @@ def main():
     stages = ctx.profile_read()
     ctx.profile(False)
 
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tv = torch.tensor([float(my_variants)], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
-    dt_max, total_variants = float(tt.item()), float(tv.item())
+    dt_max, total_variants = sharding.reduce_job(dist if use_dist else None, dt, my_variants, device="cuda")
 
     # sizes for the roofline (algorithmic bytes), this rank
     comp_bytes = sum(int(sh.off[-1].item()) for sh in shards)

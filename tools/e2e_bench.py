@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe- and inflate-inclusive) rate of the streaming pipeline: synthetic BGZF file on
+local disk -> C++ reader threads -> pinned ring -> hipMemcpyAsync -> encode + compress -> framed chunks
+back on the host.  Reported in DESIGN.md next to the HBM-resident number of bench.py; never bench.py's
+`value`."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", type=int, default=60000)
+    ap.add_argument("--samples", type=int, default=2504)
+    ap.add_argument("--kind", choices=["bgzf", "gzip", "plain"], default="bgzf")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--block-mb", type=int, default=64)
+    ap.add_argument("--repeat", type=int, default=3)
+    a = ap.parse_args()
+    import torch  # noqa: F401
+    from haplohyped_varawareml_amd import device as dev, synth
+    from haplohyped_varawareml_amd.pipeline import stream_file
+    from haplohyped_varawareml_amd.reader import write_bgzf
+    import gzip
+    ctx = dev.Context(0)
+    tab = synth.variant_table(22, a.variants, a.samples)
+    t, n = ctx.synth_fixed("chr22", tab, a.samples, seed=22)
+    text = t.cpu().numpy().tobytes()
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    p = os.path.join(d, "chr22.filtered.vcf.gz")
+    t0 = time.time()
+    if a.kind == "bgzf":
+        write_bgzf(p, text, level=1)
+    elif a.kind == "gzip":
+        with gzip.open(p, "wb", compresslevel=1) as f:
+            f.write(text)
+    else:
+        open(p, "wb").write(text)
+    prep = time.time() - t0
+    best = None
+    for _ in range(a.repeat):
+        sink = []
+        fs = stream_file(ctx, p, region="chr22", block_bytes=a.block_mb << 20, n_threads=a.threads,
+                         on_columns=lambda G, n, framed: sink.append(framed[0].size))
+        if best is None or fs.seconds < best.seconds:
+            best = fs
+    out = dict(kind=a.kind, variants=a.variants, samples=a.samples, text_bytes=best.text_bytes,
+               file_bytes=os.path.getsize(p), seconds=best.seconds, variants_per_s=best.n_kept / best.seconds,
+               text_GBps=best.text_bytes / best.seconds / 1e9, ratio=best.raw_bytes / max(best.compressed_bytes, 1),
+               host_cores=os.cpu_count(), threads=a.threads or os.cpu_count(), prep_seconds=prep)
+    print(json.dumps(out))
+    os.remove(p)
+    os.rmdir(d)
+
+
+if __name__ == "__main__":
+    main()
