@@ -177,11 +177,15 @@ def main():
     dom_ms_per_launch = stages[dom]["ms"] / max(stages[dom]["launches"], 1)
     dom_bytes_per_launch = alg[dom] / max(len(shards), 1)                     # one launch per shard per step
     achieved = dom_bytes_per_launch / (dom_ms_per_launch * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected
+    # in separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch size
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            per_variant = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_variant")
+            if per_variant and S == 2504:
+                traffic = per_variant * my_variants / max(len(shards), 1)
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_blocks", "encode": "k_encode_tiles", "index": "k_index_newlines",

@@ -313,7 +313,11 @@ __device__ __forceinline__ Own6 lds_load6(const uint8_t *in, uint32_t pos)
 }
 
 // number of equal leading bytes (0..4) given x = a ^ b
-__device__ __forceinline__ uint32_t eq_bytes(uint32_t x) { return x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u; }
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t x)
+{
+    const uint32_t t = (uint32_t)(__ffs((int)x) - 1) >> 3;  // x == 0 -> 0xFFFFFFFF >> 3
+    return t < 4u ? t : 4u;
+}
 
 __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x * 0x8081u) >> 23; }  // exact for x < 65536
 
@@ -660,14 +664,16 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
                 const uint32_t off = pos - cand;
                 oq[q] = (uint8_t)(off & 0xFFu);
                 oq[q + 1u] = (uint8_t)(off >> 8);
-                if (llx | mlx) {
-                    if (llx) {
+                if (llx == 1u) oq[1u] = (uint8_t)(ll - 15u);          // common: one extension byte
+                if (mlx == 1u) oq[q + 2u] = (uint8_t)(mlc - 15u);
+                if ((llx | mlx) > 1u) {                                 // rare: 255-runs (long literal runs / matches)
+                    if (llx > 1u) {
                         const uint32_t rem = ll - 15u;
-                        for (uint32_t k = 0; k < llx; ++k) oq[1u + k] = (k == llx - 1u) ? (uint8_t)(rem % 255u) : (uint8_t)255u;
+                        for (uint32_t k = 0; k < llx; ++k) oq[1u + k] = (k == llx - 1u) ? (uint8_t)(rem - 255u * (llx - 1u)) : (uint8_t)255u;
                     }
-                    if (mlx) {
+                    if (mlx > 1u) {
                         const uint32_t rem = mlc - 15u;
-                        for (uint32_t k = 0; k < mlx; ++k) oq[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem % 255u) : (uint8_t)255u;
+                        for (uint32_t k = 0; k < mlx; ++k) oq[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem - 255u * (mlx - 1u)) : (uint8_t)255u;
                     }
                 }
             }
