@@ -10,7 +10,7 @@ OK = 0
 BLOSC1 = 1
 BLOSC2 = 2
 N_STAGES = 8
-STAGE_NAMES = ["index", "fixed", "encode", "general", "lz4", "frame", "decode", "reserved"]
+STAGE_NAMES = ["index", "fixed", "encode", "general", "lz4", "frame", "decode", "onehot"]
 
 
 class HhgtError(RuntimeError):
@@ -25,6 +25,13 @@ class HhgtError(RuntimeError):
 class Layout(C.Structure):
     _fields_ = [("n_samples", C.c_int32), ("sc", C.c_int32), ("vc", C.c_int32), ("reserved", C.c_int32),
                 ("v_capacity", C.c_uint64)]
+
+
+class Window(C.Structure):     # hhgt_window
+    _fields_ = [("ref_ptr", C.c_uint64), ("ref_len", C.c_uint64), ("win_start", C.c_int64),
+                ("var_start_ptr", C.c_uint64), ("var_ref_ptr", C.c_uint64), ("var_alt_ptr", C.c_uint64),
+                ("geno_ptr", C.c_uint64), ("geno_first", C.c_uint32), ("var_lo", C.c_uint32),
+                ("var_hi", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class EncodeStats(C.Structure):
@@ -70,6 +77,7 @@ def load():
     L.hhgt_compress_bound.argtypes = [u64, u64, i32, i32]
     L.hhgt_compress_chunks.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, u64, vp, C.POINTER(u64), vp]
     L.hhgt_decompress_chunks.argtypes = [vp, vp, vp, u64, u64, i32, i32, vp, C.POINTER(u64), vp]
+    L.hhgt_onehot_windows.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, i32, vp, vp, vp]
     L.hhgt_profile_enable.argtypes = [vp, i32]
     L.hhgt_profile_reset.argtypes = [vp]
     L.hhgt_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhhgt.so")
 SOURCES = ["scan.hip", "index.hip", "encode.hip", "lz4.hip", "frame.hip", "decode.hip", "synth.hip",
-           "reader.hip", "api.hip"]
+           "reader.hip", "onehot.hip", "api.hip"]
 
 
 def _hipcc():

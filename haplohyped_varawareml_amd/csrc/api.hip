@@ -92,7 +92,7 @@ extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
                       &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff,
                       &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_off,
                       &c->counters, &c->region, &c->lz_scratch, &c->lz_csize, &c->fr_bsize, &c->fr_csize,
-                      &c->fr_flags, &c->dec_bad};
+                      &c->fr_flags, &c->dec_bad, &c->oh_ovl, &c->oh_lut};
     for (DevBuf *b : bufs) b->release();
     if (c->h_counters) hipHostFree(c->h_counters);
     for (auto &p : c->pending) {

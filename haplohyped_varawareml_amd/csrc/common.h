@@ -90,7 +90,7 @@ struct hhgt_ctx {
     DevBuf counters;       // DevCounters
     DevBuf region;         // RegionFilter
     // compress workspaces
-    DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad;
+    DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut;
     // pinned host mirror for counters
     DevCounters *h_counters = nullptr;
     // last encode's chrom runs (host)

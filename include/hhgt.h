@@ -144,6 +144,33 @@ int hhgt_decompress_chunks(hhgt_ctx *ctx, const void *d_src, const uint64_t *d_c
                            void *d_dst, uint64_t *n_bad, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Consumer side (BASELINE config 5): one-hot haplotype windows straight into a device tensor.
+ * Replaces the per-item numpy work of RandomHaplotypeDataset.__getitem__ / encode_haplotypes /
+ * encode_sequence (/root/reference/src/datasets/haplotype_dataset.py:54-110,
+ * src/utils/common_utils.py:84-103): reference bases of the window, overlaid at every variant of the
+ * window with ALT where the donor's allele == 1 and with the VCF REF base otherwise (:99-100), then
+ * one-hot float32 [n_items, seq_len, n_channels] for both haplotypes.
+ * All pointers inside hhgt_window are DEVICE addresses.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t ref_ptr;       /* uint8 bases (ASCII) of the contig                                   */
+    uint64_t ref_len;       /* bases available; window positions beyond it read as 'N'             */
+    int64_t win_start;      /* 0-based genomic start of the window                                 */
+    uint64_t var_start_ptr; /* uint32 start[] of the group's kept variants (sorted, 0-based)       */
+    uint64_t var_ref_ptr;   /* uint8 ref[]                                                         */
+    uint64_t var_alt_ptr;   /* uint8 alt[]                                                         */
+    uint64_t geno_ptr;      /* int8 pairs (h0,h1) of THIS donor; element 0 belongs to variant geno_first */
+    uint32_t geno_first;
+    uint32_t var_lo, var_hi; /* variants with win_start <= start < win_start + seq_len             */
+    uint32_t reserved;
+} hhgt_window;
+
+/* lut: 256 host bytes, base byte -> channel index (0..n_channels-1) or 255 for "no channel"
+ * (all-zero row).  d_hap1/d_hap2: float32 [n_items][seq_len][n_channels]. */
+int hhgt_onehot_windows(hhgt_ctx *ctx, const hhgt_window *d_items, uint32_t n_items, uint32_t seq_len,
+                        const uint8_t *lut, int n_channels, float *d_hap1, float *d_hap2, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-stage device timing (HIP events on the launch stream).  Stages are indexed by HHGT_STAGE_*.
  * hhgt_profile_read returns accumulated milliseconds and launch counts since the last reset.
  * ------------------------------------------------------------------------------------------- */
@@ -154,6 +181,7 @@ int hhgt_decompress_chunks(hhgt_ctx *ctx, const void *d_src, const uint64_t *d_c
 #define HHGT_STAGE_LZ4 4      /* shuffle + LZ4 block encode                                      */
 #define HHGT_STAGE_FRAME 5    /* Blosc2 framing / compaction                                     */
 #define HHGT_STAGE_DECODE 6   /* chunk decode                                                    */
+#define HHGT_STAGE_ONEHOT 7   /* one-hot haplotype windows                                       */
 #define HHGT_N_STAGES 8
 int hhgt_profile_enable(hhgt_ctx *ctx, int on);
 int hhgt_profile_reset(hhgt_ctx *ctx);

@@ -1,0 +1,116 @@
+"""RandomHaplotypeDataset (BASELINE config 5).  CPU part restates the reference's helper tests
+(/root/reference/tests/test_utils.py:11-32); the -m gpu part compares the device one-hot tensors with a
+numpy restatement of the documented semantics (haplotype_dataset.py:11-16,86-110, common_utils.py:84-103).
+No reference outputs exist for this consumer: parity unpinned (see dataset.py docstring)."""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_parse_encode_dict_like_reference():
+    from haplohyped_varawareml_amd.dataset import parse_encode_dict
+    assert parse_encode_dict(None) == {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}          # test_utils.py:11-15
+    assert parse_encode_dict(["A", "C", "G", "T"]) == {"A": 0, "C": 1, "G": 2, "T": 3}   # :17-21
+    assert parse_encode_dict("ACGTN")["N"] == 4
+    custom = {"A": 1, "C": 2, "G": 3, "T": 4}
+    assert parse_encode_dict(custom) == custom                                          # :23-27
+    with pytest.raises(TypeError):                                                      # :29-32
+        parse_encode_dict(123)
+
+
+def test_midpoint_region_and_lut():
+    from haplohyped_varawareml_amd.dataset import calculate_midpoint_region, channel_lut
+    assert calculate_midpoint_region(10_000_000, 10_001_000, 1000) == (10_000_000, 10_001_000)
+    assert calculate_midpoint_region(100, 200, 1000) == (0, 650)
+    lut, C = channel_lut(None)
+    assert C == 5 and [lut[ord(c)] for c in "ACGTNacgtnRX-"] == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 4, 4, 4]
+    lut4, C4 = channel_lut("ACGT")
+    assert C4 == 4 and lut4[ord("N")] == 255 and lut4[ord("g")] == 2
+
+
+def numpy_expected(ds, items):
+    """documented semantics, one item at a time, plain numpy"""
+    L, C = ds.seq_length, ds.n_channels
+    out1 = np.zeros((len(items), L, C), np.float32)
+    out2 = np.zeros_like(out1)
+    for b, it in enumerate(items):
+        seq = np.full(L, ord("N"), np.uint8)
+        ref = ds.reference_genome.contigs.get(it["chrom"])
+        if ref is not None:
+            a, e = it["start"], min(it["start"] + L, len(ref))
+            if e > a:
+                seq[: e - a] = ref[a:e]
+        h = [seq.copy(), seq.copy()]
+        if it["group"] in ds.store.meta["groups"]:
+            start, vref, valt, _ = ds.store.variants(it["group"])
+            row = ds.store.sample_row(it["group"], it["donor"])
+            for j in range(len(start)):
+                off = int(start[j]) - it["start"]
+                if 0 <= off < L:
+                    for k in (0, 1):
+                        h[k][off] = valt[j] if row[j, k] == 1 else vref[j]
+        for k, dst in ((0, out1), (1, out2)):
+            ch = ds.lut[h[k]]
+            ok = ch < C
+            dst[b, np.nonzero(ok)[0], ch[ok]] = 1.0
+    return out1, out2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq_length,batch,spec", [(1000, 4, None), (4096, 3, "ACGT"), (1001, 2, None)])
+def test_dataset_matches_numpy_restatement(ctx, tmp_path, golden_dir, seq_length, batch, spec):
+    import shutil
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    from haplohyped_varawareml_amd.dataset import RandomHaplotypeDataset
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr22.filtered.vcf.gz"), vcf_dir / "chr22.filtered.vcf.gz")
+    samples = os.path.join(golden_dir, "ipscs_samples_test.txt")
+    store = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "out"), samples, 2, 1).run()
+    # synthetic reference covering the fixture's coordinates (the reference's chr22.fasta is 1 Mbp while
+    # its VCF/BED sit at 10-20 Mbp): 20 Mbp of random bases with a few n/N
+    rng = np.random.default_rng(1)
+    seq = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[rng.integers(0, 9, 20_100_000)]
+    np.savez(tmp_path / "ref.npz", chr22=seq)
+    ds = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), store, str(tmp_path / "ref.npz"), samples,
+                                encode_spec=spec, seed=42, batch_size=batch, seq_length=seq_length, ctx=ctx)
+    assert len(ds) == 20                                   # BED rows (test_integration.py:46-55)
+    C = 5 if spec is None else len(spec)
+    n_var_total = 0
+    for _ in range(3):
+        h1, h2 = ds[0]
+        assert h1.shape == h2.shape == (batch, seq_length, C) and h1.dtype == h2.dtype == __import__("torch").float32
+        e1, e2 = numpy_expected(ds, ds.last_items)
+        assert np.array_equal(h1.cpu().numpy(), e1) and np.array_equal(h2.cpu().numpy(), e2)
+        assert float(h1.sum()) <= batch * seq_length
+        n_var_total += sum(it["var_hi"] - it["var_lo"] for it in ds.last_items)
+    assert n_var_total > 0 or seq_length < 2000
+    ds.close()
+
+
+@pytest.mark.gpu
+def test_dataset_config5_shape(ctx, tmp_path, golden_dir):
+    """BASELINE config 5: seq_length=131072, batch=32 -> two [32, 131072, 5] float32 tensors on the GPU"""
+    import shutil
+    import torch
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    from haplohyped_varawareml_amd.dataset import RandomHaplotypeDataset
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr22.filtered.vcf.gz"), vcf_dir / "chr22.filtered.vcf.gz")
+    samples = os.path.join(golden_dir, "ipscs_samples_test.txt")
+    store = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "out"), samples, 2, 1).run()
+    rng = np.random.default_rng(2)
+    np.savez(tmp_path / "ref.npz", chr22=np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20_200_000)])
+    ds = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), store, str(tmp_path / "ref.npz"), samples,
+                                seed=42, batch_size=32, seq_length=131072, ctx=ctx)
+    h1, h2 = ds[0]
+    assert h1.is_cuda and h1.shape == (32, 131072, 5)
+    # every position has exactly one hot channel (reference bases are ACGT here)
+    assert torch.equal(h1.sum(-1), torch.ones(32, 131072, device=h1.device))
+    assert torch.equal(h2.sum(-1), torch.ones(32, 131072, device=h1.device))
+    e1, e2 = numpy_expected(ds, ds.last_items[:2])
+    assert np.array_equal(h1[:2].cpu().numpy(), e1) and np.array_equal(h2[:2].cpu().numpy(), e2)
+    assert sum(it["var_hi"] - it["var_lo"] for it in ds.last_items) > 32     # windows do contain variants
+    ds.close()
