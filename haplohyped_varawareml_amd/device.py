@@ -212,6 +212,36 @@ class Context:
             torch.cuda.current_stream().synchronize()
         return text[:nbytes], nbytes
 
+    def synth_mixed(self, contig, table, n_samples, seed, v_first=0, with_header=True, names=None):
+        """config-4 style shard (synth.mixed_table) rendered in HBM -> (text uint8 tensor, nbytes, line_off)"""
+        from . import synth
+        lib = self.lib
+        if not hasattr(lib, "_synth_mixed_bound"):
+            lib.hhgt_synth_render_mixed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 6 + [
+                C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_uint64, C.c_void_p]
+            lib._synth_mixed_bound = True
+        S = int(n_samples)
+        V = len(table["pos"])
+        head = synth.header_text(contig, names or synth.sample_names(S)) if with_header else b""
+        ll = synth.mixed_line_lengths(contig, table, S)
+        off = np.zeros(V + 1, dtype=np.uint64)
+        off[0] = len(head)
+        off[1:] = len(head) + np.cumsum(ll).astype(np.uint64)
+        nbytes = int(off[-1])
+        with torch.cuda.device(self.device):
+            text = torch.empty(nbytes + 16, dtype=torch.uint8, device=self.device)
+            if head:
+                text[:len(head)] = torch.frombuffer(bytearray(head), dtype=torch.uint8).to(self.device)
+            up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(self.device)
+            d_off, d_pos = up(off, np.int64), up(table["pos"], np.int32)
+            d_ref8, d_alt8 = up(table["ref8"], np.int64), up(table["alt8"], np.int64)
+            d_meta, d_thr = up(table["meta"], np.int32), up(table["thr"], np.int32)
+            check(lib.hhgt_synth_render_mixed(self.h, _ptr(text), nbytes, _ptr(d_off), _ptr(d_pos), _ptr(d_ref8),
+                                              _ptr(d_alt8), _ptr(d_meta), _ptr(d_thr), V, int(v_first),
+                                              contig.encode(), S, int(seed), _stream()))
+            torch.cuda.current_stream().synchronize()
+        return text[:nbytes], nbytes, off
+
     # ---- profiling -----------------------------------------------------------------------------
     def profile(self, on=True):
         check(self.lib.hhgt_profile_enable(self.h, 1 if on else 0))

@@ -199,3 +199,125 @@ def render_mixed(contig, n_variants, n_samples, seed, names=None, p_multi=0.10, 
     if not trailing_newline:
         text = text[: -len(eol)]
     return text.encode()
+
+
+# ---------------------------------------------------------------------------------------------------
+# config-4 style workloads with a device renderer (csrc/synth.hip k_synth_mixed) and this numpy mirror
+def mixed_table(seed, n_variants, n_samples, p_multi=0.10, p_weird=0.02, p_dp=0.20):
+    """variant_table + REF/ALT strings (<= 8 bytes), n_alt, with_dp, kept (passes isSNP)."""
+    V = int(n_variants)
+    t = variant_table(seed, V, n_samples)
+    u, u2, u3, u5 = _u01(seed, 4, V), _u01(seed, 6, V), _u01(seed, 7, V), _u01(seed, 5, V)
+    ref_s = np.zeros((V, 8), np.uint8)
+    alt_s = np.zeros((V, 8), np.uint8)
+    ref_len = np.ones(V, np.uint32)
+    alt_len = np.ones(V, np.uint32)
+    n_alt = np.ones(V, np.uint32)
+    ref_s[:, 0] = t["ref"]
+    alt_s[:, 0] = t["alt"]
+    acgt = b"ACGT"
+    multi = u < p_multi
+    weird = (~multi) & (u < p_multi + p_weird)
+    for v in np.nonzero(multi)[0]:
+        k = 2 + int(u2[v] < 0.3)
+        others = [b for b in acgt if b != t["ref"][v]][:k]
+        sx = b",".join(bytes([b]) for b in others)
+        alt_s[v, :len(sx)] = np.frombuffer(sx, np.uint8)
+        alt_len[v] = len(sx)
+        n_alt[v] = k
+    for v in np.nonzero(weird)[0]:
+        c = int(u3[v] * 5)
+        if c == 0:
+            ref_s[v, 1] = ord("T"); ref_len[v] = 2
+        elif c == 1:
+            alt_s[v, 1] = ord("G"); alt_len[v] = 2
+        elif c == 2:
+            alt_s[v, 0] = ord("*")
+        elif c == 3:
+            alt_s[v, :5] = np.frombuffer(b"<DEL>", np.uint8); alt_len[v] = 5
+        else:
+            alt_s[v, 0] = t["alt"][v] + 32          # lower case
+    with_dp = (u5 < p_dp)
+    t.update(ref_s=ref_s, alt_s=alt_s, ref_len=ref_len, alt_len=alt_len, n_alt=n_alt, with_dp=with_dp,
+             kept=(~multi) & (~weird),
+             meta=(ref_len | (alt_len << 4) | (n_alt << 8) | (with_dp.astype(np.uint32) << 12)).astype(np.uint32),
+             ref8=np.ascontiguousarray(ref_s).view("<u8").reshape(-1), alt8=np.ascontiguousarray(alt_s).view("<u8").reshape(-1))
+    return t
+
+
+def mixed_line_lengths(contig, t, n_samples):
+    fmt_len = np.where(t["with_dp"], 5, 2)
+    fw = np.where(t["with_dp"], 7, 4)
+    return (len(contig) + ndigits(t["pos"]) + t["ref_len"].astype(np.int64) + t["alt_len"].astype(np.int64) + 16
+            + fmt_len + int(n_samples) * fw)
+
+
+def mixed_calls(seed, t, n_samples, v_idx, v_first=0):
+    """per-call text pieces for variants v_idx: (c0, sep, c1, dp) uint8 arrays [len(v_idx), S]"""
+    S = int(n_samples)
+    v_idx = np.asarray(v_idx, dtype=np.uint64)
+    key = mix64(np.uint64(seed) + GOLD)
+    A5 = np.uint64(0xA5A5A5A5A5A5A5A5)
+    with np.errstate(over="ignore"):
+        kv = key ^ ((v_idx + np.uint64(v_first)) * KV)
+        s2 = np.arange(S, dtype=np.uint64) * np.uint64(2)
+        r0 = mix64(kv[:, None] ^ (s2 * GOLD)[None, :])
+        r1 = mix64(kv[:, None] ^ ((s2 + np.uint64(1)) * GOLD)[None, :])
+        r2 = mix64(kv[:, None] ^ (s2 * GOLD)[None, :] ^ A5)
+    thr = t["thr"][v_idx.astype(np.int64)].astype(np.uint64)[:, None]
+    na = t["n_alt"][v_idx.astype(np.int64)].astype(np.uint64)[:, None]
+
+    def allele(r):
+        hit = (r >> np.uint64(32)) < thr
+        multi = np.uint64(1) + ((r >> np.uint64(8)) & np.uint64(0xFFFFFF)) % np.maximum(na, np.uint64(1))
+        return np.where(hit, np.where(na > 1, multi, np.uint64(1)), np.uint64(0)).astype(np.int64)
+
+    a0, a1 = allele(r0), allele(r1)
+    mm = (r2 & np.uint64(0xFFFF)).astype(np.int64)
+    both = mm < 1311
+    half = (~both) & (mm < 1639)
+    which1 = ((r2 >> np.uint64(16)) & np.uint64(1)).astype(bool)
+    miss0 = both | (half & ~which1)
+    miss1 = both | (half & which1)
+    c0 = np.where(miss0, ord("."), 48 + a0).astype(np.uint8)
+    c1 = np.where(miss1, ord("."), 48 + a1).astype(np.uint8)
+    sep = np.where(((r2 >> np.uint64(20)) & np.uint64(0xFFFF)).astype(np.int64) < 3277, ord("/"), ord("|")).astype(np.uint8)
+    dp = (10 + ((r2 >> np.uint64(40)) % np.uint64(90)).astype(np.int64)).astype(np.uint8)
+    g0 = np.where(miss0, -9, a0).astype(np.int8)
+    g1 = np.where(miss1, -9, a1).astype(np.int8)
+    return c0, sep, c1, dp, np.stack([g0, g1], axis=-1)
+
+
+def mixed_expected_G(seed, t, n_samples, v_idx, v_first=0):
+    """int8 [S, len(v_idx), 2] the encode path must produce for the KEPT variants v_idx"""
+    return mixed_calls(seed, t, n_samples, v_idx, v_first)[4].transpose(1, 0, 2).copy()
+
+
+def render_mixed_numpy(contig, t, n_samples, seed, v_first=0, with_header=True, names=None):
+    """CPU mirror of hhgt_synth_render_mixed (small sizes) -> (bytes, line_off)"""
+    S = int(n_samples)
+    V = len(t["pos"])
+    head = header_text(contig, names or sample_names(S)) if with_header else b""
+    ll = mixed_line_lengths(contig, t, S)
+    off = np.zeros(V + 1, dtype=np.uint64)
+    off[0] = len(head)
+    off[1:] = len(head) + np.cumsum(ll).astype(np.uint64)
+    out = bytearray(int(off[-1]))
+    out[:len(head)] = head
+    c0, sep, c1, dp, _ = mixed_calls(seed, t, S, np.arange(V), v_first)
+    cb = contig.encode()
+    for v in range(V):
+        ref = bytes(t["ref_s"][v, :t["ref_len"][v]])
+        alt = bytes(t["alt_s"][v, :t["alt_len"][v]])
+        fmt = b"GT:DP" if t["with_dp"][v] else b"GT"
+        cols = []
+        for s in range(S):
+            f = bytes([c0[v, s], sep[v, s], c1[v, s]])
+            if t["with_dp"][v]:
+                f += b":%02d" % int(dp[v, s])
+            cols.append(f)
+        line = b"\t".join([cb, str(int(t["pos"][v])).encode(), b".", ref, alt, b".", b"PASS", b".", fmt] + cols) + b"\n"
+        o = int(off[v])
+        assert len(line) == int(off[v + 1]) - o, (v, len(line), int(off[v + 1]) - o)
+        out[o:o + len(line)] = line
+    return bytes(out), off

@@ -24,6 +24,21 @@ int hhgt_synth_render_fixed(hhgt_ctx *ctx, void *d_text, uint64_t text_cap, cons
                             const uint32_t *d_thr, uint64_t n_variants, uint64_t v_first, const char *contig,
                             int n_samples, uint64_t seed, void *stream);
 
+/* BASELINE config 4 shape: multiallelic records (ALT "C,G", "C,G,T"), indel / '*' / '<DEL>' / lower-case
+ * ALTs that the isSNP filter must drop, missing ('.') and half-missing calls, '/' separators and records
+ * with GT:DP columns ("a|b:dd").  Per variant i: d_ref8/d_alt8 hold the REF / ALT text (up to 8 bytes,
+ * little-endian packed), d_meta = ref_len | alt_len << 4 | n_alt << 8 | with_dp << 12.
+ * Per call (v, s), with r_h = mix64(kv ^ (2s+h)*GOLD) and r2 = mix64(kv ^ (2s)*GOLD ^ 0xA5A5A5A5A5A5A5A5):
+ *   allele_h = (r_h >> 32) < thr ? (n_alt > 1 ? 1 + ((r_h >> 8) & 0xFFFFFF) % n_alt : 1) : 0
+ *   (r2 & 0xFFFF) < 1311 -> both '.';  < 1639 -> allele ((r2 >> 16) & 1) is '.'
+ *   ((r2 >> 20) & 0xFFFF) < 3277 -> separator '/', else '|';   DP = 10 + (r2 >> 40) % 90
+ * Line i is strlen(contig) + digits(pos) + ref_len + alt_len + 16 + fmt_len + S * (with_dp ? 7 : 4)
+ * bytes (fmt_len = 2 or 5).  CPU mirror: haplohyped_varawareml_amd/synth.py (mixed_*). */
+int hhgt_synth_render_mixed(hhgt_ctx *ctx, void *d_text, uint64_t text_cap, const uint64_t *d_line_off,
+                            const uint32_t *d_pos, const uint64_t *d_ref8, const uint64_t *d_alt8,
+                            const uint32_t *d_meta, const uint32_t *d_thr, uint64_t n_variants, uint64_t v_first,
+                            const char *contig, int n_samples, uint64_t seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
