@@ -536,7 +536,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
 }
 
 __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out)
+                                                         uint32_t hashlog, uint8_t *__restrict__ out, uint32_t dbg)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < (1u << hashlog) / 2u; i += 64u) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
@@ -582,7 +582,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
                 len += act ? nm : 0u;
                 act = act && nm == 4u;
             }
-            if (__ballot(act) != 0ull) {  // second batch: bytes 20..35
+            if (!(dbg & 2u) && __ballot(act) != 0ull) {  // second batch: bytes 20..35
                 const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -657,7 +657,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const uint32_t size = sel ? 3u + llx + ll + mlx : 0u;
             uint32_t total;
             const uint32_t so = wave_incl_scan_dpp(size, lane, &total) - size;
-            if (sel) {
+            if (sel && !(dbg & 1u)) {
                 uint8_t *oq = out + op + so;
                 oq[0] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u));
                 const uint32_t q = 1u + llx + ll;
@@ -684,9 +684,9 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const int base = (int)(so + 1u + llx) - (int)anc;   // on selected lanes: literal area base - anchor
             const int bn = __shfl(base, (int)nxt, 64);
             const bool covered = has_below && pos < prev_end;
-            if (!sel && !covered && has_above && pos >= anchor) out[(int)op + bn + (int)pos] = (uint8_t)(d & 0xFFu);
+            if (!sel && !covered && has_above && pos >= anchor && !(dbg & 1u)) out[(int)op + bn + (int)pos] = (uint8_t)(d & 0xFFu);
             // literals of the first sequence that lie in front of this window (pending from earlier windows)
-            if (anchor < p) {
+            if (anchor < p && !(dbg & 1u)) {
                 const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
                 const uint32_t ll0 = p + first - anchor;
                 const uint32_t llx0 = ll0 >= 15u ? div255(ll0 - 15u) + 1u : 0u;
@@ -774,12 +774,12 @@ __global__ __launch_bounds__(1024) void k_lz4_blocks(const uint8_t *__restrict__
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + ((size_t)wave << hashlog);
 #ifdef LZ_ONLY_V3
-        uint32_t cs = lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
+        uint32_t cs = lz4_wave_compress_v4(in, neblock, tb, hashlog, out, algo >> 8);
 #else
-        uint32_t cs = algo == 1u   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                      : algo == 2u ? lz4_wave_compress_v2(in, neblock, tb, hashlog, out)
-                      : algo == 3u ? lz4_wave_compress_v3(in, neblock, tb, hashlog, out)
-                                   : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
+        uint32_t cs = (algo & 255u) == 1u   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
+                      : (algo & 255u) == 2u ? lz4_wave_compress_v2(in, neblock, tb, hashlog, out)
+                      : (algo & 255u) == 3u ? lz4_wave_compress_v3(in, neblock, tb, hashlog, out)
+                                   : lz4_wave_compress_v4(in, neblock, tb, hashlog, out, algo >> 8);
 #endif
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];

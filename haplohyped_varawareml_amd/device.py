@@ -10,12 +10,13 @@ from . import _lib
 from ._lib import BLOSC1, BLOSC2, EncodeStats, HhgtError, Layout, check
 
 # default on-disk geometry: one HDF5 chunk = 64 samples x 8192 variants x 2 haplotypes (1 MiB);
-# one Blosc2 block = one sample row of the chunk (16 KiB -> two 8 KiB byte planes, which lets 16
-# LZ4 waves stay resident per CU); typesize 2 = one diploid call
+# one Blosc2 block = half a sample row of the chunk = 4096 diploid calls (8 KiB -> two 4 KiB byte
+# planes: ~10 KiB of LDS per LZ4 workgroup, so ~30 waves stay resident per CU — the kernel is latency /
+# issue bound, not HBM bound); typesize 2 = one diploid call
 DEFAULT_SC = 64
 DEFAULT_VC = 8192
 DEFAULT_TYPESIZE = 2
-DEFAULT_BLOCKSIZE = DEFAULT_VC * 2
+DEFAULT_BLOCKSIZE = 8192
 
 
 def make_layout(n_samples, v_capacity, sc=DEFAULT_SC, vc=DEFAULT_VC):

@@ -138,7 +138,7 @@ def _emit(ctx, stage, n_cols, col_bytes, chunk_nbytes, on_columns, compress, fmt
     framed = None
     fs.raw_bytes += cols.numel()
     if compress:
-        dst, off, total = ctx.compress(cols, chunk_nbytes, typesize=dev.DEFAULT_TYPESIZE, blocksize=lay.vc * 2, fmt=fmt)
+        dst, off, total = ctx.compress(cols, chunk_nbytes, typesize=dev.DEFAULT_TYPESIZE, blocksize=min(lay.vc * 2, dev.DEFAULT_BLOCKSIZE), fmt=fmt)
         framed = (dst[:total].cpu().numpy(), off.cpu().numpy().astype(np.uint64))
         fs.compressed_bytes += total
     if on_columns:

@@ -29,7 +29,7 @@ class StoreWriter:
         os.makedirs(path, exist_ok=True)
         self.meta = dict(format="hhgt-store", version=1, cohort_name=cohort_name, samples=list(samples),
                          donor_ids=list(donor_ids) if donor_ids is not None else list(samples),
-                         sc=int(sc), vc=int(vc), typesize=int(typesize), blocksize=int(vc) * 2,
+                         sc=int(sc), vc=int(vc), typesize=int(typesize), blocksize=min(int(vc) * 2, 8192),
                          codec="blosc2: byte-shuffle + LZ4 block format", groups={})
         self._cur = None
 
