@@ -289,9 +289,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
 // -------------------------------------------------------------------------------------------------
 // zero columns [c0, c1) (variant index inside the chunk column) of rows [r0, r1) (sample index inside
 // the padded sample axis) of chunk column vcol
-__global__ __launch_bounds__(256) void k_zero_rect(LayoutDev lay, uint64_t vcol, uint32_t r0, uint32_t r1,
+__global__ __launch_bounds__(256) void k_zero_rect(LayoutDev lay, uint64_t vcol0, uint32_t r0, uint32_t r1,
                                                    uint64_t c0, uint64_t c1, int8_t *__restrict__ G)
 {
+    const uint64_t vcol = vcol0 + blockIdx.z;   // one launch covers a range of chunk columns
     const uint32_t r = r0 + blockIdx.y;
     if (r >= r1) return;
     const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (r >> lay.sc_log2);
@@ -352,11 +353,12 @@ int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t
     }
     // (b) sample padding rows of every touched chunk column
     if (S_pad > lay.S) {
-        for (uint64_t vcol = vcol_begin; vcol < vcol_end; ++vcol) {
-            uint64_t segs = (lay.Vc * 2 + 15) / 16 + 1;
-            uint32_t gx = (uint32_t)((segs + 255) / 256);
-            if (gx > 1024) gx = 1024;
-            hipLaunchKernelGGL(k_zero_rect, dim3(gx, S_pad - lay.S), dim3(256), 0, st, lay, vcol, lay.S, S_pad, 0ull,
+        uint64_t segs = (lay.Vc * 2 + 15) / 16 + 1;
+        uint32_t gx = (uint32_t)((segs + 255) / 256);
+        if (gx > 64) gx = 64;
+        for (uint64_t v0 = vcol_begin; v0 < vcol_end; v0 += 65535) {
+            uint32_t nz = (uint32_t)(vcol_end - v0 < 65535 ? vcol_end - v0 : 65535);
+            hipLaunchKernelGGL(k_zero_rect, dim3(gx, S_pad - lay.S, nz), dim3(256), 0, st, lay, v0, lay.S, S_pad, 0ull,
                                lay.Vc, d_G);
         }
     }
