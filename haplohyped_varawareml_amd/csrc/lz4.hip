@@ -125,173 +125,8 @@ __device__ __forceinline__ uint32_t lz4_wave_compress(const uint8_t *in, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// v2: window-parallel greedy LZ4.  Per 64-position window every lane (a) looks its position up in the
-// hash table and verifies 4 bytes, (b) extends ITS OWN match up to LZ_CAP bytes with dword compares,
-// then (c) the greedy left-to-right selection of non-overlapping matches runs on the SCALAR unit
-// (ballot mask + s_ff1 + v_readlane, no LDS round trips) and (d) all selected sequences of the window
-// are emitted at once: sizes -> wave prefix sum -> every lane writes its own token / offset / length
-// bytes, literals between matches are scattered by one lane-parallel store.  Only matches that outrun
-// LZ_CAP (long zero runs) and the literal run in front of a window's first match use wave loops.
-#define LZ_CAP_ITERS 8u  // per-lane extension limit: 4 + 4 * 8 = 36 bytes
-
-__device__ __forceinline__ uint32_t lz4_wave_compress_v2(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = lane; i < (1u << hashlog) / 2u; i += 64u) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
-    uint32_t op = 0, anchor = 0, cur = 0;
-    if (n > LZ_MFLIMIT) {
-        const uint32_t mflimit = n - LZ_MFLIMIT, matchlimit = n - LZ_LASTLITERALS;
-        const uint32_t hshift = 32u - hashlog;
-        uint32_t p = 0;
-        while (p <= mflimit) {
-            const uint32_t pos = p + lane;
-            const bool valid = pos <= mflimit;
-            const uint32_t d = valid ? lds_load4(in, pos) : 0u;
-            const uint32_t h = (d * 2654435761u) >> hshift;
-            const uint32_t cand = valid ? (uint32_t)tab[h] : 0u;
-            if (valid) tab[h] = (uint16_t)pos;
-            const uint32_t r = lds_load4(in, cand);
-            const bool ok = valid && cand < pos && r == d && pos >= cur;
-            const unsigned long long M = __ballot(ok);
-            if (M == 0ull) {
-                p += 64u;
-                continue;
-            }
-            // (b) per-lane forward extension, 4 bytes per step
-            uint32_t len = LZ_MINMATCH;
-            bool act = ok;
-#pragma unroll 1
-            for (uint32_t it = 0; it < LZ_CAP_ITERS; ++it) {
-                if (__ballot(act) == 0ull) break;
-                const uint32_t a = lds_load4(in, pos + len), b = lds_load4(in, cand + len);
-                const uint32_t x = a ^ b;
-                const uint32_t nm = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
-                if (act) {
-                    len += nm;
-                    act = nm == 4u;
-                }
-            }
-            const uint32_t maxlen = matchlimit - pos;  // >= 7 for valid lanes
-            bool lng = act;
-            if (ok && len >= maxlen) {
-                len = maxlen;
-                lng = false;
-            }
-            const unsigned long long LNG = __ballot(lng);
-            // (c) greedy selection on the scalar unit
-            unsigned long long SEL = 0ull, COV = 0ull;
-            uint32_t lcur = cur > p ? cur - p : 0u;
-            for (;;) {
-                const unsigned long long m = lcur < 64u ? (M >> lcur) << lcur : 0ull;
-                if (m == 0ull) break;
-                const uint32_t i = (uint32_t)__ffsll((long long)m) - 1u;
-                uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)i);
-                if ((LNG >> i) & 1ull) {
-                    // match outruns the per-lane cap: finish it cooperatively, 256 bytes per step
-                    const uint32_t ps = p + i;
-                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)i);
-                    uint32_t ml = li;
-                    for (;;) {
-                        const uint32_t k = ml + 4u * lane;
-                        uint32_t nm = 0u;
-                        if (ps + k < matchlimit) {
-                            const uint32_t x = lds_load4(in, ps + k) ^ lds_load4(in, c + k);
-                            nm = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
-                            const uint32_t room = matchlimit - (ps + k);
-                            nm = nm < room ? nm : room;
-                        }
-                        const unsigned long long stop = __ballot(nm < 4u);
-                        if (stop == 0ull) {
-                            ml += 256u;
-                            continue;
-                        }
-                        const uint32_t f = (uint32_t)__ffsll((long long)stop) - 1u;
-                        ml += 4u * f + (uint32_t)__builtin_amdgcn_readlane((int)nm, (int)f);
-                        break;
-                    }
-                    li = ml;
-                    len = lane == i ? ml : len;
-                }
-                SEL |= 1ull << i;
-                const uint32_t e = i + li;
-                COV |= (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << i) - 1ull);
-                lcur = e;
-            }
-            if (SEL == 0ull) {
-                p += 64u;
-                continue;
-            }
-            // (d) emit every selected sequence of this window
-            const bool sel = (SEL >> lane) & 1ull;
-            const uint32_t endp = pos + len;
-            const unsigned long long below = SEL & ((1ull << lane) - 1ull);
-            const uint32_t prev = below ? 63u - (uint32_t)__clzll((long long)below) : lane;
-            const uint32_t prev_end = (uint32_t)__shfl((int)endp, (int)prev, 64);
-            const uint32_t anc = below ? prev_end : anchor;
-            const uint32_t ll = pos - anc, mlc = len - LZ_MINMATCH;
-            const uint32_t llx = ll >= 15u ? (ll - 15u) / 255u + 1u : 0u;
-            const uint32_t mlx = mlc >= 15u ? (mlc - 15u) / 255u + 1u : 0u;
-            const uint32_t size = sel ? 1u + llx + ll + 2u + mlx : 0u;
-            uint32_t inc = size;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)inc, dd, 64);
-                if (lane >= (uint32_t)dd) inc += t;
-            }
-            const uint32_t so = inc - size;
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            if (sel) {
-                uint8_t *o = out + op + so;
-                o[0] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u));
-                if (llx) {
-                    const uint32_t rem = ll - 15u;
-                    for (uint32_t k = 0; k < llx; ++k) o[1u + k] = (k == llx - 1u) ? (uint8_t)(rem % 255u) : (uint8_t)255u;
-                }
-                const uint32_t q = 1u + llx + ll;
-                const uint32_t off = pos - cand;
-                o[q] = (uint8_t)(off & 0xFFu);
-                o[q + 1u] = (uint8_t)(off >> 8);
-                if (mlx) {
-                    const uint32_t rem = mlc - 15u;
-                    for (uint32_t k = 0; k < mlx; ++k) o[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem % 255u) : (uint8_t)255u;
-                }
-            }
-            // literals in front of the window's first match (may reach back over earlier windows)
-            const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
-            {
-                const uint32_t ll0 = (uint32_t)__builtin_amdgcn_readlane((int)ll, (int)first);
-                const uint32_t dst0 = op + 1u + (uint32_t)__builtin_amdgcn_readlane((int)llx, (int)first);
-                for (uint32_t k = lane; k < ll0; k += 64u) out[dst0 + k] = in[anchor + k];
-            }
-            // literals between matches: one scattered store for the whole window
-            {
-                const int base = (int)(so + 1u + llx) - (int)anc;
-                const unsigned long long above = lane < 63u ? SEL >> (lane + 1u) : 0ull;
-                const bool lit = !((COV >> lane) & 1ull) && lane > first && above != 0ull;
-                const uint32_t nxt = above ? lane + 1u + (uint32_t)(__ffsll((long long)above) - 1) : lane;
-                const int bn = __shfl(base, (int)nxt, 64);
-                if (lit) out[(int)op + bn + (int)pos] = (uint8_t)(d & 0xFFu);
-            }
-            op += total;
-            cur = p + lcur;
-            anchor = cur;
-            p = cur > p + 64u ? cur : p + 64u;
-        }
-    }
-    {
-        const uint32_t ll = n - anchor;
-        if (lane == 0) out[op] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
-        uint32_t q = op + 1u;
-        if (ll >= 15u) q = emit_len(out, q, ll - 15u, lane);
-        for (uint32_t k = lane; k < ll; k += 64u) out[q + k] = in[anchor + k];
-        op = q + ll;
-    }
-    return op;
-}
-
-// ---------------------------------------------------------------------------------------------
-// v3: v2 with the dependent LDS round trips cut down (the kernel is latency/issue bound, not HBM bound):
+// helpers shared by the window-parallel encoder (v2/v3 history: DESIGN.md §3.1).  v3 cut the dependent
+// LDS round trips down (the kernel is latency/issue bound, not HBM bound):
 //   * each lane fetches 24 bytes of its own position and 24 bytes of its candidate in ONE batch of
 //     ds_read2_b32 and measures its match up to 20 bytes from registers; a second batch (to 36 bytes)
 //     runs only when some lane is still matching,
@@ -320,185 +155,6 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t x)
 }
 
 __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x * 0x8081u) >> 23; }  // exact for x < 65536
-
-__device__ __forceinline__ uint32_t lz4_wave_compress_v3(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = lane; i < (1u << hashlog) / 2u; i += 64u) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
-    uint32_t op = 0, anchor = 0, cur = 0;
-    if (n > LZ_MFLIMIT) {
-        const uint32_t mflimit = n - LZ_MFLIMIT, matchlimit = n - LZ_LASTLITERALS;
-        const uint32_t hshift = 32u - hashlog;
-        uint32_t p = 0;
-        Own6 own = lds_load6(in, lane);
-        while (p <= mflimit) {
-            const uint32_t pos = p + lane;
-            const bool valid = pos <= mflimit;
-            const uint32_t sh = pos & 3u;
-            uint32_t o[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) o[k] = __builtin_amdgcn_alignbyte(own.w[k + 1], own.w[k], sh);
-            const uint32_t d = o[0];
-            const uint32_t h = (d * 2654435761u) >> hshift;
-            const uint32_t cand = valid ? (uint32_t)tab[h] : 0u;
-            if (valid) tab[h] = (uint16_t)pos;
-            const Own6 cw = lds_load6(in, cand);
-            const uint32_t csh = cand & 3u;
-            uint32_t x[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], csh);
-            const bool ok = valid && cand < pos && x[0] == 0u && pos >= cur;
-            const unsigned long long M = __ballot(ok);
-            if (M == 0ull) {
-                p += 64u;
-                own = lds_load6(in, p + lane);
-                continue;
-            }
-            // match length from registers: 4 + equal bytes of x[1..4] (up to 20)
-            uint32_t len = 4u;
-            bool act = ok;
-#pragma unroll
-            for (int k = 1; k < 5; ++k) {
-                const uint32_t nm = eq_bytes(x[k]);
-                if (act) {
-                    len += nm;
-                    act = nm == 4u;
-                }
-            }
-            if (__ballot(act) != 0ull) {  // second batch: bytes 20..35
-                const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t xx = __builtin_amdgcn_alignbyte(o2.w[k + 1], o2.w[k], sh) ^
-                                        __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], csh);
-                    const uint32_t nm = eq_bytes(xx);
-                    if (act) {
-                        len += nm;
-                        act = nm == 4u;
-                    }
-                }
-            }
-            const uint32_t maxlen = matchlimit - pos;
-            bool lng = act;
-            if (ok && len >= maxlen) {
-                len = maxlen;
-                lng = false;
-            }
-            const unsigned long long LNG = __ballot(lng);
-            // greedy selection + output layout on the scalar unit
-            unsigned long long SEL = 0ull, COV = 0ull;
-            uint32_t lcur = cur > p ? cur - p : 0u;
-            uint32_t so_run = 0u, a_run = anchor, first_ll = 0u, first_llx = 0u;
-            uint32_t v_so = 0u, v_anc = 0u;
-            for (;;) {
-                const unsigned long long m = lcur < 64u ? (M >> lcur) << lcur : 0ull;
-                if (m == 0ull) break;
-                const uint32_t i = (uint32_t)__ffsll((long long)m) - 1u;
-                uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)i);
-                if ((LNG >> i) & 1ull) {
-                    const uint32_t ps = p + i;
-                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)i);
-                    uint32_t ml = li;
-                    for (;;) {
-                        const uint32_t k = ml + 4u * lane;
-                        uint32_t nm = 0u;
-                        if (ps + k < matchlimit) {
-                            nm = eq_bytes(lds_load4(in, ps + k) ^ lds_load4(in, c + k));
-                            const uint32_t room = matchlimit - (ps + k);
-                            nm = nm < room ? nm : room;
-                        }
-                        const unsigned long long stop = __ballot(nm < 4u);
-                        if (stop == 0ull) {
-                            ml += 256u;
-                            continue;
-                        }
-                        const uint32_t f = (uint32_t)__ffsll((long long)stop) - 1u;
-                        ml += 4u * f + (uint32_t)__builtin_amdgcn_readlane((int)nm, (int)f);
-                        break;
-                    }
-                    li = ml;
-                    len = lane == i ? ml : len;
-                }
-                const uint32_t posi = p + i;
-                const uint32_t ll = posi - a_run, mlc = li - LZ_MINMATCH;
-                const uint32_t llx = ll >= 15u ? div255(ll - 15u) + 1u : 0u;
-                const uint32_t mlx = mlc >= 15u ? div255(mlc - 15u) + 1u : 0u;
-                if (SEL == 0ull) {
-                    first_ll = ll;
-                    first_llx = llx;
-                }
-                v_so = lane == i ? so_run : v_so;
-                v_anc = lane == i ? a_run : v_anc;
-                so_run += 1u + llx + ll + 2u + mlx;
-                a_run = posi + li;
-                SEL |= 1ull << i;
-                const uint32_t e = i + li;
-                COV |= (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << i) - 1ull);
-                lcur = e;
-            }
-            if (SEL == 0ull) {
-                p += 64u;
-                own = lds_load6(in, p + lane);
-                continue;
-            }
-            // next window's own bytes: request now, consumed after the emission below
-            const uint32_t ncur = p + lcur;
-            const uint32_t np = ncur > p + 64u ? ncur : p + 64u;
-            const Own6 nown = lds_load6(in, np + lane);
-            // emit: every selected lane writes its own sequence header / offset / length bytes
-            const bool sel = (SEL >> lane) & 1ull;
-            if (sel) {
-                const uint32_t ll = pos - v_anc, mlc = len - LZ_MINMATCH;
-                const uint32_t llx = ll >= 15u ? div255(ll - 15u) + 1u : 0u;
-                const uint32_t mlx = mlc >= 15u ? div255(mlc - 15u) + 1u : 0u;
-                uint8_t *oq = out + op + v_so;
-                oq[0] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u));
-                if (llx) {
-                    const uint32_t rem = ll - 15u;
-                    for (uint32_t k = 0; k < llx; ++k) oq[1u + k] = (k == llx - 1u) ? (uint8_t)(rem % 255u) : (uint8_t)255u;
-                }
-                const uint32_t q = 1u + llx + ll;
-                const uint32_t off = pos - cand;
-                oq[q] = (uint8_t)(off & 0xFFu);
-                oq[q + 1u] = (uint8_t)(off >> 8);
-                if (mlx) {
-                    const uint32_t rem = mlc - 15u;
-                    for (uint32_t k = 0; k < mlx; ++k) oq[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem % 255u) : (uint8_t)255u;
-                }
-            }
-            const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
-            {
-                const uint32_t dst0 = op + 1u + first_llx;
-                for (uint32_t k = lane; k < first_ll; k += 64u) out[dst0 + k] = in[anchor + k];
-            }
-            {
-                const uint32_t llq = pos - v_anc;
-                const uint32_t llxq = llq >= 15u ? div255(llq - 15u) + 1u : 0u;
-                const int base = (int)(v_so + 1u + llxq) - (int)v_anc;
-                const unsigned long long above = lane < 63u ? SEL >> (lane + 1u) : 0ull;
-                const bool lit = !((COV >> lane) & 1ull) && lane > first && above != 0ull;
-                const uint32_t nxt = above ? lane + 1u + (uint32_t)(__ffsll((long long)above) - 1) : lane;
-                const int bn = __shfl(base, (int)nxt, 64);
-                if (lit) out[(int)op + bn + (int)pos] = (uint8_t)(d & 0xFFu);
-            }
-            op += so_run;
-            cur = ncur;
-            anchor = ncur;
-            p = np;
-            own = nown;
-        }
-    }
-    {
-        const uint32_t ll = n - anchor;
-        if (lane == 0) out[op] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
-        uint32_t q = op + 1u;
-        if (ll >= 15u) q = emit_len(out, q, ll - 15u, lane);
-        for (uint32_t k = lane; k < ll; k += 64u) out[q + k] = in[anchor + k];
-        op = q + ll;
-    }
-    return op;
-}
 
 // ---------------------------------------------------------------------------------------------
 // v4: PMC counters of v3 showed ~325 SALU + ~190 VALU instructions per 64-byte window — the shared
@@ -536,15 +192,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
 }
 
 __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out, uint32_t dbg)
+                                                         uint32_t hashlog, uint8_t *__restrict__ out)
 {
+    // PMC (profiles/r01_pmc_lz4_v4_sq_*.csv) puts this loop at ~0.75 scalar instructions per cycle per CU:
+    // the CU's single scalar unit is the bound.  Hence: per-lane predicates are kept as 0 / ~0 integers in
+    // VGPRs (mask logic on VCC/SGPR pairs is scalar work), lane-divergent `if`s are merged or replaced by
+    // address selects, and the greedy-parse loop is written so that it compiles to ~8 scalar instructions.
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = lane; i < (1u << hashlog) / 2u; i += 64u) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
-    // per-lane constant masks: lanes strictly below / strictly above this lane
+    for (uint32_t i = lane; i < (1u << hashlog) / 2u + 1u; i += 64u) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
+    const uint32_t dummy_slot = 1u << hashlog;  // table entry hashed positions never use (insert sink)
     const uint32_t below_lo = lane >= 32u ? 0xFFFFFFFFu : ((1u << lane) - 1u);
     const uint32_t below_hi = lane <= 32u ? 0u : ((1u << (lane - 32u)) - 1u);
     const uint32_t above_lo = lane >= 31u ? 0u : (0xFFFFFFFFu << (lane + 1u));
     const uint32_t above_hi = lane < 32u ? 0xFFFFFFFFu : (lane == 63u ? 0u : (0xFFFFFFFFu << (lane - 31u)));
+    const uint32_t lane_bit_lo = lane < 32u ? 1u << lane : 0u, lane_bit_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
     uint32_t op = 0, anchor = 0, cur = 0;
     if (n > LZ_MFLIMIT) {
         const uint32_t mflimit = n - LZ_MFLIMIT, matchlimit = n - LZ_LASTLITERALS;
@@ -553,60 +214,62 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
         Own6 own = lds_load6(in, lane);
         while (p <= mflimit) {
             const uint32_t pos = p + lane;
-            const bool valid = pos <= mflimit;
             const uint32_t sh = pos & 3u;
             uint32_t o[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) o[k] = __builtin_amdgcn_alignbyte(own.w[k + 1], own.w[k], sh);
             const uint32_t d = o[0];
             const uint32_t h = (d * 2654435761u) >> hshift;
-            const uint32_t cand = valid ? (uint32_t)tab[h] : 0u;
-            if (valid) tab[h] = (uint16_t)pos;
+            const uint32_t cand = (uint32_t)tab[h];
+            tab[pos <= mflimit ? h : dummy_slot] = (uint16_t)pos;
             const Own6 cw = lds_load6(in, cand);
             const uint32_t csh = cand & 3u;
             uint32_t x[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) x[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], csh);
-            const bool ok = valid && cand < pos && x[0] == 0u && pos >= cur;
-            const unsigned long long M = __ballot(ok);
+            // ok <=> pos <= mflimit, cand < pos, 4 bytes equal, pos >= cur   (one compare feeds the ballot)
+            const uint32_t bad = x[0] | ((mflimit - pos) >> 31) | ((pos - cand - 1u) >> 31) | ((pos - cur) >> 31);
+            const unsigned long long M = __ballot(bad == 0u);
             if (M == 0ull) {
                 p += 64u;
                 own = lds_load6(in, p + lane);
                 continue;
             }
+            uint32_t am = bad == 0u ? 0xFFFFFFFFu : 0u;  // "still matching" as a lane mask in a VGPR
             uint32_t len = 4u;
-            bool act = ok;
 #pragma unroll
             for (int k = 1; k < 5; ++k) {
                 const uint32_t nm = eq_bytes(x[k]);
-                len += act ? nm : 0u;
-                act = act && nm == 4u;
+                len += nm & am;
+                am &= 0u - (nm >> 2);
             }
-            if (!(dbg & 2u) && __ballot(act) != 0ull) {  // second batch: bytes 20..35
+            if (__ballot(am != 0u) != 0ull) {  // second batch: bytes 20..35
                 const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t xx = __builtin_amdgcn_alignbyte(o2.w[k + 1], o2.w[k], sh) ^
                                         __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], csh);
                     const uint32_t nm = eq_bytes(xx);
-                    len += act ? nm : 0u;
-                    act = act && nm == 4u;
+                    len += nm & am;
+                    am &= 0u - (nm >> 2);
                 }
             }
             const uint32_t maxlen = matchlimit - pos;
-            const bool clipped = len >= maxlen;
-            len = clipped ? maxlen : len;
-            const unsigned long long LNG = __ballot(act && !clipped);
-            // ---- greedy parse: the only serial part, scalar unit
+            am = len >= maxlen ? 0u : am;        // clipped at the end of the stream: not "long"
+            len = len < maxlen ? len : maxlen;
+            const unsigned long long LNG = __ballot(am != 0u);
+            // ---- greedy parse: the only serial part (scalar unit)
             unsigned long long SEL = 0ull;
             uint32_t lcur = cur > p ? cur - p : 0u;
             uint32_t last = 0u;
-            for (;;) {
-                const unsigned long long m = lcur < 64u ? M & (~0ull << lcur) : 0ull;
-                if (m == 0ull) break;
-                last = (uint32_t)__ffsll((long long)m) - 1u;
-                SEL |= 1ull << last;
-                lcur = last + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)last);
+            if (lcur < 64u) {
+                do {
+                    const unsigned long long m = M & (~0ull << lcur);
+                    if (m == 0ull) break;
+                    last = (uint32_t)__ffsll((long long)m) - 1u;
+                    SEL |= 1ull << last;
+                    lcur = last + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)last);
+                } while (lcur < 64u);
             }
             if (SEL == 0ull) {
                 p += 64u;
@@ -644,29 +307,44 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const Own6 nown = lds_load6(in, np + lane);
             // ---- layout, lane-parallel from SEL
             const uint32_t sel_lo = (uint32_t)SEL, sel_hi = (uint32_t)(SEL >> 32);
-            const bool sel = lane < 32u ? (sel_lo >> lane) & 1u : (sel_hi >> (lane - 32u)) & 1u;
+            const uint32_t selm = ((sel_lo & lane_bit_lo) | (sel_hi & lane_bit_hi)) ? 0xFFFFFFFFu : 0u;
             const uint32_t b_lo = sel_lo & below_lo, b_hi = sel_hi & below_hi;
-            const bool has_below = (b_lo | b_hi) != 0u;
             const uint32_t prev = b_hi ? 63u - (uint32_t)__clz((int)b_hi) : 31u - (uint32_t)__clz((int)(b_lo | 1u));
             const uint32_t endp = pos + len;
-            const uint32_t prev_end = (uint32_t)__shfl((int)endp, (int)prev, 64);
-            const uint32_t anc = has_below ? prev_end : anchor;  // end of the previous selected match
-            const uint32_t ll = pos - anc, mlc = len - LZ_MINMATCH;   // meaningful on selected lanes
+            const uint32_t prev_end_raw = (uint32_t)__shfl((int)endp, (int)prev, 64);
+            const uint32_t anc = (b_lo | b_hi) ? prev_end_raw : anchor;  // end of the previous selected match
+            const uint32_t ll = pos - anc, mlc = len - LZ_MINMATCH;       // meaningful on selected lanes
             const uint32_t llx = ll >= 15u ? div255(ll - 15u) + 1u : 0u;
             const uint32_t mlx = mlc >= 15u ? div255(mlc - 15u) + 1u : 0u;
-            const uint32_t size = sel ? 3u + llx + ll + mlx : 0u;
+            const uint32_t size = (3u + llx + ll + mlx) & selm;
             uint32_t total;
             const uint32_t so = wave_incl_scan_dpp(size, lane, &total) - size;
-            if (sel && !(dbg & 1u)) {
-                uint8_t *oq = out + op + so;
-                oq[0] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u));
+            // literals: lanes not covered by a selected match that have a selected match above them
+            const uint32_t a_lo = sel_lo & above_lo, a_hi = sel_hi & above_hi;
+            const uint32_t nxt = a_lo ? (uint32_t)__ffs((int)a_lo) - 1u : (a_hi ? 31u + (uint32_t)__ffs((int)a_hi) : lane);
+            const int base = (int)(so + 1u + llx) - (int)anc;   // on selected lanes: literal area base - anchor
+            const int bn = __shfl(base, (int)nxt, 64);
+            uint8_t *const wout = out + op;
+            if (selm) {
+                // token, then (same lane, program order) the optional one-byte extensions; a lane without an
+                // extension re-writes its own token / high offset byte instead of branching
+                uint8_t *oq = wout + so;
+                const uint32_t token = ((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u);
                 const uint32_t q = 1u + llx + ll;
                 const uint32_t off = pos - cand;
+                oq[0] = (uint8_t)token;
+                oq[llx == 1u ? 1u : 0u] = (uint8_t)(llx == 1u ? ll - 15u : token);
                 oq[q] = (uint8_t)(off & 0xFFu);
                 oq[q + 1u] = (uint8_t)(off >> 8);
-                if (llx == 1u) oq[1u] = (uint8_t)(ll - 15u);          // common: one extension byte
-                if (mlx == 1u) oq[q + 2u] = (uint8_t)(mlc - 15u);
-                if ((llx | mlx) > 1u) {                                 // rare: 255-runs (long literal runs / matches)
+                oq[mlx == 1u ? q + 2u : q + 1u] = (uint8_t)(mlx == 1u ? mlc - 15u : off >> 8);
+            } else if ((a_lo | a_hi) && pos >= anc) {
+                // not selected, something selected above, not inside the previous selected match
+                wout[bn + (int)pos] = (uint8_t)(d & 0xFFu);
+            }
+            if (__ballot((llx | mlx) > 1u) != 0ull) {  // rare: 255-runs (long literal runs / long matches)
+                if (selm && (llx | mlx) > 1u) {
+                    uint8_t *oq = wout + so;
+                    const uint32_t q = 1u + llx + ll;
                     if (llx > 1u) {
                         const uint32_t rem = ll - 15u;
                         for (uint32_t k = 0; k < llx; ++k) oq[1u + k] = (k == llx - 1u) ? (uint8_t)(rem - 255u * (llx - 1u)) : (uint8_t)255u;
@@ -677,16 +355,8 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
                     }
                 }
             }
-            // literals: lanes not covered by a selected match that have a selected match above them
-            const uint32_t a_lo = sel_lo & above_lo, a_hi = sel_hi & above_hi;
-            const bool has_above = (a_lo | a_hi) != 0u;
-            const uint32_t nxt = a_lo ? (uint32_t)__ffs((int)a_lo) - 1u : (a_hi ? 31u + (uint32_t)__ffs((int)a_hi) : lane);
-            const int base = (int)(so + 1u + llx) - (int)anc;   // on selected lanes: literal area base - anchor
-            const int bn = __shfl(base, (int)nxt, 64);
-            const bool covered = has_below && pos < prev_end;
-            if (!sel && !covered && has_above && pos >= anchor && !(dbg & 1u)) out[(int)op + bn + (int)pos] = (uint8_t)(d & 0xFFu);
             // literals of the first sequence that lie in front of this window (pending from earlier windows)
-            if (anchor < p && !(dbg & 1u)) {
+            if (anchor < p) {
                 const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
                 const uint32_t ll0 = p + first - anchor;
                 const uint32_t llx0 = ll0 >= 15u ? div255(ll0 - 15u) + 1u : 0u;
@@ -772,15 +442,9 @@ __global__ __launch_bounds__(1024) void k_lz4_blocks(const uint8_t *__restrict__
         const uint8_t *in = data + (size_t)wave * pstride;
         const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
         uint8_t *out = scratch + sidx * slot_bytes;
-        uint16_t *tb = tabs + ((size_t)wave << hashlog);
-#ifdef LZ_ONLY_V3
-        uint32_t cs = lz4_wave_compress_v4(in, neblock, tb, hashlog, out, algo >> 8);
-#else
-        uint32_t cs = (algo & 255u) == 1u   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                      : (algo & 255u) == 2u ? lz4_wave_compress_v2(in, neblock, tb, hashlog, out)
-                      : (algo & 255u) == 3u ? lz4_wave_compress_v3(in, neblock, tb, hashlog, out)
-                                   : lz4_wave_compress_v4(in, neblock, tb, hashlog, out, algo >> 8);
-#endif
+        uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
+        uint32_t cs = (algo & 255u) == 1u ? lz4_wave_compress(in, neblock, tb, hashlog, out)
+                                          : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
             cs = neblock;
@@ -813,14 +477,14 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     // relative to the smallest one (512 entries); 160 KiB LDS and 32 waves per CU.
     static const int hl_env = getenv("HHGT_LZ4_HASHLOG") ? atoi(getenv("HHGT_LZ4_HASHLOG")) : 0;
     auto occ = [&](uint32_t hl) {
-        size_t l = data_bytes + ((size_t)nwaves << (hl + 1));
+        size_t l = data_bytes + (size_t)nwaves * ((2u << hl) + 4u);
         size_t by_lds = (160 * 1024) / l, by_waves = 32 / nwaves;
         return by_lds < by_waves ? by_lds : by_waves;
     };
     uint32_t hashlog = 12;
     while (hashlog > 9 && occ(hashlog) < occ(9)) --hashlog;
     if (hl_env >= 8 && hl_env <= 13) hashlog = (uint32_t)hl_env;
-    const size_t lds = data_bytes + ((size_t)nwaves << (hashlog + 1));
+    const size_t lds = data_bytes + (size_t)nwaves * ((2u << hashlog) + 4u);
     if (lds > 160 * 1024 - 64) {
         hhgt_set_error("lz4: block of %d bytes x typesize %d does not fit LDS", blocksize, typesize);
         return HHGT_ERR_ARG;
