@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--vc", type=int, default=dev.DEFAULT_VC, help="variants per chunk (chunk = 64 x vc x 2 bytes)")
     ap.add_argument("--blocksize", type=int, default=dev.DEFAULT_BLOCKSIZE, help="Blosc2 block bytes")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encode/compress overlap")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one GPU in rehearsals")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
     return ap.parse_args()
@@ -156,8 +157,12 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     torch.cuda.set_device(local_rank)
     ctx = dev.Context(local_rank)
     S = args.samples

@@ -397,8 +397,13 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
                        (unsigned long long)h.n_kept, (unsigned long long)v_base, (unsigned long long)L.v_capacity);
         return HHGT_ERR_CAPACITY;
     }
+    if (h.n_chrom_runs > MAX_CHROM_RUNS) {
+        hhgt_set_error("encode: %llu CHROM runs in one text block (limit %u): the input is not sorted by contig",
+                       (unsigned long long)h.n_chrom_runs, MAX_CHROM_RUNS);
+        return HHGT_ERR_CAPACITY;
+    }
     // CHROM runs (names are a few bytes each; read back lazily but while the text is still resident)
-    uint32_t n_runs = (uint32_t)(h.n_chrom_runs < MAX_CHROM_RUNS ? h.n_chrom_runs : MAX_CHROM_RUNS);
+    uint32_t n_runs = (uint32_t)h.n_chrom_runs;
     if (n_runs) {
         std::vector<uint64_t> first(n_runs);
         std::vector<uint32_t> off(n_runs);

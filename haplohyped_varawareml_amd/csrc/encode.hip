@@ -15,6 +15,7 @@
 // k_encode_general (anything else: GT:DP columns, multi-digit alleles, haploid calls ...): one wave
 //   per line, tab-rank by ballot/prefix over 1 KiB pieces, htslib GT rule per field.
 #include "common.h"
+#include <stdlib.h>
 
 // -------------------------------------------------------------------------------------------------
 // one "a|b\t" field in a dword (little endian: a, sep, b, terminator) -> h0 | h1 << 8 ; bit 31 = not
@@ -39,40 +40,48 @@ __device__ __forceinline__ uint32_t parse_field(uint32_t x)
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 
 #define FILL_FIELD 0x09307C30u  // "0|0\t"
+#ifndef TILE_G
+#define TILE_G 16  // lines whose 16-byte loads are in flight together per wave (1 KiB each)
+#endif
 
-__global__ __launch_bounds__(256, 2) void k_encode_tiles(const uint8_t *__restrict__ text, uint64_t n,
-                                                         const uint32_t *__restrict__ k_soff,
-                                                         const uint32_t *__restrict__ k_meta, uint64_t v_base,
-                                                         LayoutDev lay, int8_t *__restrict__ G,
-                                                         uint32_t *__restrict__ redo_list,
-                                                         uint32_t *__restrict__ redo_flag, DevCounters *cnt)
+// TV = variants per tile (128 or 64).  LDS = 256 rows x 2*TV bytes (64 / 32 KiB): TV = 64 lets four
+// workgroups share a CU, so the load, transpose and store phases of different tiles overlap.
+template <int TV>
+__global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
+    const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ k_soff,
+    const uint32_t *__restrict__ k_meta, uint64_t v_base, LayoutDev lay, int8_t *__restrict__ G,
+    uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag, DevCounters *cnt)
 {
-    __shared__ uint4 tile[TILE_S * 16];  // 256 rows x 256 B, 16-byte slots XOR-swizzled by (row >> 2) & 7
+    constexpr int LW = TV / 4;        // lines per wave
+    constexpr int SLOTS = TV / 8;     // 16-byte slots per LDS row
+    constexpr int WSL = SLOTS / 4;    // slots per row owned by one wave
+    constexpr int G_ = LW < TILE_G ? LW : TILE_G;
+    __shared__ uint4 tile[TILE_S * SLOTS];  // 256 rows x 2*TV B, 16-byte slots XOR-swizzled by (row >> 2) & 7
     const uint32_t n_kept = (uint32_t)cnt->n_kept;
-    const uint64_t gv0 = (v_base / TILE_V + blockIdx.x) * (uint64_t)TILE_V;  // first global column of tile
-    const long long k0 = (long long)gv0 - (long long)v_base;                 // batch-local kept index of it
+    const uint64_t gv0 = (v_base / TV + blockIdx.x) * (uint64_t)TV;  // first global column of tile
+    const long long k0 = (long long)gv0 - (long long)v_base;         // batch-local kept index of it
     if (k0 >= (long long)n_kept || gv0 >= lay.v_capacity) return;
     const uint32_t s0 = blockIdx.y * TILE_S;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t S = lay.S;
-    const uint32_t ls = s0 + 4u * lane;                       // first sample of this lane
+    const uint32_t ls = s0 + 4u * lane;                                 // first sample of this lane
     const uint32_t nval = ls >= S ? 0u : (S - ls >= 4u ? 4u : S - ls);  // samples this lane owns
     const uint32_t last_q = (S - 1u >= ls && S - 1u < ls + 4u) ? S - 1u - ls : 4u;  // which dword is sample S-1
 
-    uint32_t acc[4][16];
+    uint32_t acc[4][LW / 2];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[q][c] = 0;
+        for (int c = 0; c < LW / 2; ++c) acc[q][c] = 0;
 
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        uint4 raw[8];
-        bool lvalid[8];
+    for (int g = 0; g < LW / G_; ++g) {
+        uint4 raw[G_];
+        bool lvalid[G_];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long k = k0 + (long long)(w * 32u + g * 8 + j);
+        for (int j = 0; j < G_; ++j) {
+            const long long k = k0 + (long long)(w * LW + g * G_ + j);
             bool valid = k >= 0 && k < (long long)n_kept;
             uint32_t meta = 0, soff = 0;
             if (valid) {
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_tiles(const uint8_t *__restri
             raw[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < G_; ++j) {
             uint32_t x[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
             uint32_t bad = 0;
 #pragma unroll
@@ -119,13 +128,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_tiles(const uint8_t *__restri
                 if ((uint32_t)q == last_q) xx = (xx & 0x00FFFFFFu) | 0x09000000u;
                 uint32_t r = parse_field(xx);
                 bad |= r;
-                const int col = g * 8 + j;
+                const int col = g * G_ + j;
                 acc[q][col >> 1] |= (r & 0xFFFFu) << ((col & 1) * 16);
             }
             if (lvalid[j]) {
                 unsigned long long bm = __ballot((bad & 0x80000000u) != 0u);
                 if (bm != 0ull && lane == 0) {
-                    const uint32_t k = (uint32_t)(k0 + (long long)(w * 32u + g * 8 + j));
+                    const uint32_t k = (uint32_t)(k0 + (long long)(w * LW + g * G_ + j));
                     if (atomicExch(&redo_flag[k], 1u) == 0u) {
                         unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
                         redo_list[slot] = k;
@@ -134,29 +143,30 @@ __global__ __launch_bounds__(256, 2) void k_encode_tiles(const uint8_t *__restri
             }
         }
     }
-    // registers -> LDS (sample-major rows).  Wave w owns byte columns [64w, 64w+64) of every row.
+    // registers -> LDS (sample-major rows).  Wave w owns byte columns [w * TV/2, (w+1) * TV/2) of every row.
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t row = 4u * lane + q;
         const uint32_t swz = (row >> 2) & 7u;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t slot = (w * 4u + c) ^ swz;
-            tile[row * 16u + slot] = make_uint4(acc[q][c * 4 + 0], acc[q][c * 4 + 1], acc[q][c * 4 + 2], acc[q][c * 4 + 3]);
+        for (int c = 0; c < WSL; ++c) {
+            const uint32_t slot = (w * WSL + c) ^ (swz & (SLOTS - 1));
+            tile[row * SLOTS + slot] = make_uint4(acc[q][c * 4 + 0], acc[q][c * 4 + 1], acc[q][c * 4 + 2], acc[q][c * 4 + 3]);
         }
     }
     __syncthreads();
-    // LDS -> HBM: each row leaves as one contiguous 256-byte run (16 lanes x 16 B)
-    const uint32_t c16 = threadIdx.x & 15u;
+    // LDS -> HBM: each row leaves as one contiguous 2*TV-byte run (SLOTS lanes x 16 B)
+    const uint32_t c16 = threadIdx.x & (SLOTS - 1);
     const uint64_t vcol = gv0 / lay.Vc, vin = gv0 - vcol * lay.Vc;
     const long long kfirst = k0 + (long long)c16 * 8;  // batch-local kept index of this lane's 8 columns
+    constexpr int ROWS_PER_IT = 256 / SLOTS;
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const uint32_t row = it * 16u + (threadIdx.x >> 4);
+    for (int it = 0; it < TILE_S / ROWS_PER_IT; ++it) {
+        const uint32_t row = it * ROWS_PER_IT + (threadIdx.x / SLOTS);
         const uint32_t s = s0 + row;
         if (s >= S) continue;
         const uint32_t swz = (row >> 2) & 7u;
-        uint4 v = tile[row * 16u + (c16 ^ swz)];
+        uint4 v = tile[row * SLOTS + (c16 ^ (swz & (SLOTS - 1)))];
         const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
         const uint32_t sin = s - scol * lay.Sc;
         int8_t *dst = G + ((((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull) + c16 * 16u;
@@ -317,10 +327,17 @@ int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_sof
                         uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st)
 {
     if (n_lines_bound == 0 || lay.S == 0) return HHGT_OK;
-    uint64_t tiles_v = ((v_base % TILE_V) + n_lines_bound + TILE_V - 1) / TILE_V;
+    static const int tv = getenv("HHGT_TILE_V") ? atoi(getenv("HHGT_TILE_V")) : 64;
     uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
-    hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
-                       k_meta, v_base, lay, d_G, redo_list, redo_flag, d_cnt);
+    if (tv == 128) {
+        uint64_t tiles_v = ((v_base % 128) + n_lines_bound + 127) / 128;
+        hipLaunchKernelGGL(k_encode_tiles<128>, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
+                           k_meta, v_base, lay, d_G, redo_list, redo_flag, d_cnt);
+    } else {
+        uint64_t tiles_v = ((v_base % 64) + n_lines_bound + 63) / 64;
+        hipLaunchKernelGGL(k_encode_tiles<64>, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
+                           k_meta, v_base, lay, d_G, redo_list, redo_flag, d_cnt);
+    }
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

@@ -111,26 +111,27 @@ __global__ __launch_bounds__(256) void k_scan_u64(const unsigned long long *__re
     if (threadIdx.x == 0) out[n] = carry;
 }
 
-// copy n bytes src -> dst (dst arbitrary alignment, src 4-byte aligned), whole workgroup
+// copy n bytes src -> dst (dst arbitrary alignment, src 4-byte aligned) by one wave
 __device__ __forceinline__ void wg_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n)
 {
+    const uint32_t tid = threadIdx.x & 63u, nthr = 64u;
     const uint32_t head = (uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
     if (n < 16u + head) {
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = tid; i < n; i += nthr) dst[i] = src[i];
         return;
     }
-    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    if (tid < head) dst[tid] = src[tid];
     const uint32_t nw = (n - head) >> 2;
     uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
     const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
     const uint32_t sh = head & 3u;  // src byte offset of dst word 0 (src is aligned, head < 4)
     const uint32_t src_words = (n + 3u) >> 2;  // dwords of src that hold valid bytes
-    for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
+    for (uint32_t w = tid; w < nw; w += nthr) {
         uint32_t a = s32[w], b = (sh && w + 1u < src_words) ? s32[w + 1u] : 0u;
         d32[w] = __builtin_amdgcn_alignbyte(b, a, sh);
     }
     const uint32_t done = head + (nw << 2);
-    if (threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+    if (tid < n - done) dst[done + tid] = src[done + tid];
 }
 
 __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_t *__restrict__ scratch,
@@ -139,20 +140,25 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
                                                      const uint32_t *__restrict__ bstart,
                                                      const unsigned long long *__restrict__ chunk_off,
                                                      const uint32_t *__restrict__ chunk_flags,
-                                                     uint8_t *__restrict__ dst, uint64_t dst_cap)
+                                                     uint8_t *__restrict__ dst, uint64_t dst_cap,
+                                                     uint64_t n_total_blocks)
 {
-    const uint64_t chunk = blockIdx.x / P.nblocks;
-    const uint32_t b = blockIdx.x - (uint32_t)(chunk * P.nblocks);
+    // one wave per Blosc block (blocks are a few KiB after compression: a whole workgroup per block idles)
+    const uint64_t gb = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (gb >= n_total_blocks) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t chunk = gb / P.nblocks;
+    const uint32_t b = (uint32_t)(gb - chunk * P.nblocks);
     const unsigned long long coff = chunk_off[chunk], cend = chunk_off[chunk + 1];
     if (cend > dst_cap) return;  // capacity error is reported by the host from chunk_off[n]
     uint8_t *cdst = dst + coff;
     const uint32_t memcpyed = chunk_flags[chunk];
     const uint32_t cbytes = (uint32_t)(cend - coff);
-    if (b == 0 && threadIdx.x < P.hl) {
+    if (b == 0 && lane < P.hl) {
         // header bytes (see oracle/codec_oracle.c write_header)
         const uint32_t split_flag = P.split ? 0u : BLOSC_DONT_SPLIT;
         uint32_t flags = (1u << 5) | (P.typesize > 1u ? BLOSC_DOSHUFFLE : 0u) | split_flag | (memcpyed ? BLOSC_MEMCPYED : 0u);
-        uint32_t i = threadIdx.x;
+        uint32_t i = lane;
         uint8_t v = 0;
         if (P.format == HHGT_BLOSC2) {
             if (i == 0) v = 5;
@@ -179,18 +185,18 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
         const uint8_t *s = src + chunk * P.chunk_nbytes + boff;
         uint8_t *d = cdst + P.hl + boff;
         if ((reinterpret_cast<uintptr_t>(s) & 3u) == 0) wg_copy(d, s, bsize);
-        else for (uint32_t i = threadIdx.x; i < bsize; i += blockDim.x) d[i] = s[i];
+        else for (uint32_t i = lane; i < bsize; i += 64u) d[i] = s[i];
         return;
     }
     const uint32_t bs = bstart[chunk * P.nblocks + b];
-    if (threadIdx.x < 4) cdst[P.hl + 4u * b + threadIdx.x] = (uint8_t)(bs >> (threadIdx.x * 8));
+    if (lane < 4) cdst[P.hl + 4u * b + lane] = (uint8_t)(bs >> (lane * 8));
     const bool leftover = bsize != P.blocksize;
     const uint32_t ns = (P.split && !leftover) ? P.typesize : 1u;
     uint32_t q = bs;
     for (uint32_t j = 0; j < ns; ++j) {
         const uint64_t sidx = ((uint64_t)chunk * P.nblocks + b) * P.nwaves + j;
         const uint32_t cs = csize[sidx];
-        if (threadIdx.x < 4) cdst[q + threadIdx.x] = (uint8_t)(cs >> (threadIdx.x * 8));
+        if (lane < 4) cdst[q + lane] = (uint8_t)(cs >> (lane * 8));
         wg_copy(cdst + q + 4u, scratch + sidx * P.slot_bytes, cs);
         q += 4u + cs;
     }
@@ -217,9 +223,10 @@ int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(256), 0, st,
                        reinterpret_cast<const unsigned long long *>(d_chunk_csize), n_chunks,
                        reinterpret_cast<unsigned long long *>(d_chunk_off));
-    hipLaunchKernelGGL(k_frame_write, dim3((uint32_t)(n_chunks * P.nblocks)), dim3(256), 0, st, P, d_scratch,
+    const uint64_t n_total_blocks = n_chunks * P.nblocks;
+    hipLaunchKernelGGL(k_frame_write, dim3((uint32_t)((n_total_blocks + 3) / 4)), dim3(256), 0, st, P, d_scratch,
                        d_csize, d_src, d_bstart, reinterpret_cast<const unsigned long long *>(d_chunk_off),
-                       d_chunk_flags, d_dst, dst_cap);
+                       d_chunk_flags, d_dst, dst_cap, n_total_blocks);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
