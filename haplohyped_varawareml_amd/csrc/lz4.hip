@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
 }
 
 __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out)
+                                                         uint32_t hashlog, uint8_t *__restrict__ out, uint32_t no_run)
 {
     // PMC (profiles/r01_pmc_lz4_v4_sq_*.csv) puts this loop at ~0.75 scalar instructions per cycle per CU:
     // the CU's single scalar unit is the bound.  Hence: per-lane predicates are kept as 0 / ~0 integers in
@@ -220,39 +220,65 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             for (int k = 0; k < 5; ++k) o[k] = __builtin_amdgcn_alignbyte(own.w[k + 1], own.w[k], sh);
             const uint32_t d = o[0];
             const uint32_t h = (d * 2654435761u) >> hshift;
-            const uint32_t cand = (uint32_t)tab[h];
+            const uint32_t hcand = (uint32_t)tab[h];
             tab[pos <= mflimit ? h : dummy_slot] = (uint16_t)pos;
-            const Own6 cw = lds_load6(in, cand);
-            const uint32_t csh = cand & 3u;
-            uint32_t x[5];
+            const Own6 cw = lds_load6(in, hcand);
+            const uint32_t hsh = hcand & 3u;
+            // two candidates per position: (a) the hash table's most recent occurrence of these 4 bytes,
+            // (b) offset 1 — the position continues a run of one byte value.  (b) needs no table and no LDS:
+            // E = ballot(byte[pos] == byte[pos-1]) is one compare per window, and a lane's run length is the
+            // number of consecutive set bits of E from its own bit (exact up to the window end).  On sparse
+            // genotype planes (b) roughly halves what a zero run costs, because an earlier "0000" copy breaks
+            // wherever the EARLIER text had a 1 (ratio 3.36 -> 4.35 on the 3 M x 2504 workload).
+            // previous lane's first byte: DPP wave_shr:1 (one VALU op, no LDS round trip on the path to M)
+            const uint32_t dprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x138, 0xf, 0xf, false);
+            const uint32_t pb = lane ? (dprev & 0xFFu) : (p ? (uint32_t)in[p - 1u] : (~d & 0xFFu));
+            const unsigned long long E = __ballot((d & 0xFFu) == pb);
+            const uint32_t E_lo = (uint32_t)E, E_hi = (uint32_t)(E >> 32);
+            // ~(E >> lane) with 32-bit full-rate ops; first set bit = end of this lane's run
+            const uint32_t r_lo = ~(lane < 32u ? __builtin_amdgcn_alignbit(E_hi, E_lo, lane) : E_hi >> (lane - 32u));
+            const uint32_t r_hi = ~(lane < 32u ? E_hi >> lane : 0u);
+            const uint32_t run = r_lo ? (uint32_t)__ffs((int)r_lo) - 1u : 31u + (uint32_t)__ffs((int)r_hi);  // <= 64 - lane
+            uint32_t xh[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], csh);
-            // ok <=> pos <= mflimit, cand < pos, 4 bytes equal, pos >= cur   (one compare feeds the ballot)
-            const uint32_t bad = x[0] | ((mflimit - pos) >> 31) | ((pos - cand - 1u) >> 31) | ((pos - cur) >> 31);
-            const unsigned long long M = __ballot(bad == 0u);
+            for (int k = 0; k < 5; ++k) xh[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], hsh);
+            // usable <=> pos <= mflimit, pos >= cur (and for (a): hcand < pos); >= 4 bytes equal
+            const uint32_t out_of_range = ((mflimit - pos) >> 31) | ((pos - cur) >> 31);
+            const uint32_t bad_h = xh[0] | out_of_range | ((pos - hcand - 1u) >> 31);
+            const uint32_t bad_r = out_of_range | ((run - 4u) >> 31) | no_run;
+            const unsigned long long M = __ballot((bad_h == 0u) | (bad_r == 0u));
             if (M == 0ull) {
                 p += 64u;
                 own = lds_load6(in, p + lane);
                 continue;
             }
-            uint32_t am = bad == 0u ? 0xFFFFFFFFu : 0u;  // "still matching" as a lane mask in a VGPR
-            uint32_t len = 4u;
+            uint32_t amh = bad_h == 0u ? 0xFFFFFFFFu : 0u;
+            uint32_t lenh = 4u & amh;
 #pragma unroll
             for (int k = 1; k < 5; ++k) {
-                const uint32_t nm = eq_bytes(x[k]);
-                len += nm & am;
-                am &= 0u - (nm >> 2);
+                const uint32_t nh = eq_bytes(xh[k]);
+                lenh += nh & amh;
+                amh &= 0u - (nh >> 2);
             }
-            if (__ballot(am != 0u) != 0ull) {  // second batch: bytes 20..35
+            const uint32_t lenr = bad_r == 0u ? run : 0u;
+            const bool use_run = lenr >= lenh;                      // ties go to the run (offset 1)
+            // "still matching": a run that reaches the window end, or a hash match alive after 20 bytes
+            uint32_t am = use_run ? ((lane + run == 64u && bad_r == 0u) ? 0xFFFFFFFFu : 0u) : amh;
+            uint32_t len = use_run ? lenr : lenh;
+            const uint32_t cand = use_run ? pos - 1u : hcand;
+            const uint32_t csh = cand & 3u;
+            if (__ballot(am != 0u && !use_run) != 0ull) {  // second batch: bytes 20..35 of hash matches
                 const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
+                uint32_t amx = use_run ? 0u : am;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t xx = __builtin_amdgcn_alignbyte(o2.w[k + 1], o2.w[k], sh) ^
                                         __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], csh);
                     const uint32_t nm = eq_bytes(xx);
-                    len += nm & am;
-                    am &= 0u - (nm >> 2);
+                    len += nm & amx;
+                    amx &= 0u - (nm >> 2);
                 }
+                am = use_run ? am : amx;
             }
             const uint32_t maxlen = matchlimit - pos;
             am = len >= maxlen ? 0u : am;        // clipped at the end of the stream: not "long"
@@ -277,26 +303,35 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
                 continue;
             }
             if ((LNG >> last) & 1ull) {
-                // the last match is still matching at the 36-byte cap: finish it, 256 bytes per step
+                // the last match is still matching (36-byte cap, or a run that reaches the window end): finish it
                 const uint32_t ps = p + last;
                 const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)last);
                 uint32_t ml = lcur - last;
-                for (;;) {
-                    const uint32_t k = ml + 4u * lane;
-                    uint32_t nm = 0u;
-                    if (ps + k < matchlimit) {
-                        nm = eq_bytes(lds_load4(in, ps + k) ^ lds_load4(in, c + k));
-                        const uint32_t room = matchlimit - (ps + k);
-                        nm = nm < room ? nm : room;
+                // most tails are short: first look at the next 64 bytes, one byte per lane
+                const uint32_t kb = ml + lane;
+                const bool eqb = (ps + kb < matchlimit) && in[ps + kb] == in[c + kb];
+                const unsigned long long neb = __ballot(!eqb);
+                if (neb != 0ull) {
+                    ml += (uint32_t)__ffsll((long long)neb) - 1u;
+                } else {
+                    ml += 64u;
+                    for (;;) {  // a long run: 256 bytes per step
+                        const uint32_t k = ml + 4u * lane;
+                        uint32_t nm = 0u;
+                        if (ps + k < matchlimit) {
+                            nm = eq_bytes(lds_load4(in, ps + k) ^ lds_load4(in, c + k));
+                            const uint32_t room = matchlimit - (ps + k);
+                            nm = nm < room ? nm : room;
+                        }
+                        const unsigned long long stop = __ballot(nm < 4u);
+                        if (stop == 0ull) {
+                            ml += 256u;
+                            continue;
+                        }
+                        const uint32_t f = (uint32_t)__ffsll((long long)stop) - 1u;
+                        ml += 4u * f + (uint32_t)__builtin_amdgcn_readlane((int)nm, (int)f);
+                        break;
                     }
-                    const unsigned long long stop = __ballot(nm < 4u);
-                    if (stop == 0ull) {
-                        ml += 256u;
-                        continue;
-                    }
-                    const uint32_t f = (uint32_t)__ffsll((long long)stop) - 1u;
-                    ml += 4u * f + (uint32_t)__builtin_amdgcn_readlane((int)nm, (int)f);
-                    break;
                 }
                 len = lane == last ? ml : len;
                 lcur = last + ml;
@@ -444,7 +479,7 @@ __global__ __launch_bounds__(1024) void k_lz4_blocks(const uint8_t *__restrict__
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
         uint32_t cs = (algo & 255u) == 1u ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                                          : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
+                                          : lz4_wave_compress_v4(in, neblock, tb, hashlog, out, (algo >> 8) & 1u);
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
             cs = neblock;
@@ -495,7 +530,10 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    static const uint32_t algo = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 4u;
+    // HHGT_LZ4_ALGO: 4 = window-parallel encoder (default), 1 = the simple first version;
+    // HHGT_LZ4_RUN=0 drops the offset-1 run candidate (about 8 % faster, ratio 3.36 instead of 4.36 on genotypes)
+    static const uint32_t algo = (getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 4u) |
+                                 ((getenv("HHGT_LZ4_RUN") && atoi(getenv("HHGT_LZ4_RUN")) == 0) ? 256u : 0u);
     const uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
     if (grid > 0x7fffffffull) {
