@@ -244,7 +244,17 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         for (uint32_t base = rs; base < lend; base += 1024u) {
             const uint32_t b0 = base + 16u * lane;
             uint32_t m = 0;
-            if (b0 < lend) {
+            if (b0 + 16u <= lend) {
+                // one unaligned 16-byte load + exact per-byte "== tab" mask (SWAR), 4 bits per dword
+                const u32x4_unaligned t4 = *reinterpret_cast<const u32x4_unaligned *>(text + b0);
+                const uint32_t wv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t t = wv[q] ^ 0x09090909u;
+                    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+                    m |= ((((z >> 7) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+                }
+            } else if (b0 < lend) {
                 for (uint32_t j = 0; j < 16u; ++j) {
                     uint32_t p = b0 + j;
                     if (p < lend && text[p] == '\t') m |= 1u << j;

@@ -76,6 +76,10 @@ static bool looks_bgzf(const uint8_t *p, size_t n)
 
 static int inflate_raw(z_stream *zs, const Task &t)
 {
+    if (t.src_len == t.dst_len && t.dst_len > 65536u) {  // plain-text piece: copy (uncompressed input files)
+        memcpy(t.dst, t.src, t.dst_len);
+        return 0;
+    }
     if (inflateReset(zs) != Z_OK) return -1;
     zs->next_in = const_cast<Bytef *>(t.src);
     zs->avail_in = t.src_len;
@@ -120,11 +124,30 @@ static void worker_main(hhgt_reader *r)
 }
 
 // fills dst[0, cap) with decompressed bytes; returns bytes produced (0 = end of input), <0 on error
+static long long run_batch(hhgt_reader *r);
+
+// uncompressed input: the copy into the pinned ring is split over the worker pool (one thread tops out
+// near 10 GB/s, well under what the PCIe link takes)
 static long long fill_plain(hhgt_reader *r, uint8_t *dst, size_t cap)
 {
     size_t avail = r->map_len - r->in_pos;
     size_t n = avail < cap ? avail : cap;
-    memcpy(dst, r->map + r->in_pos, n);
+    const size_t piece = 4u << 20;
+    if (n <= piece || r->workers.empty()) {
+        memcpy(dst, r->map + r->in_pos, n);
+    } else {
+        r->n_tasks.store(0);
+        r->tasks.clear();
+        for (size_t o = 0; o < n; o += piece) {
+            size_t l = n - o < piece ? n - o : piece;
+            if (l <= 65536u) {  // tail too small to be told apart from a BGZF block: copy it here
+                memcpy(dst + o, r->map + r->in_pos + o, l);
+                continue;
+            }
+            r->tasks.push_back(Task{r->map + r->in_pos + o, (uint32_t)l, dst + o, (uint32_t)l});
+        }
+        if (run_batch(r) < 0) return -1;
+    }
     r->in_pos += n;
     return (long long)n;
 }
@@ -182,29 +205,33 @@ static long long fill_bgzf(hhgt_reader *r, uint8_t *dst, size_t cap)
         produced += isize;
         r->in_pos += total;
     }
-    if (!r->tasks.empty()) {
-        r->done_tasks.store(0);
-        {
-            std::lock_guard<std::mutex> lk(r->pmu);
-            r->batch_id++;
-            r->open_gen.store(r->batch_id);
-            r->n_tasks.store(r->tasks.size());
-            r->ticket.store(r->batch_id << 32);
-        }
-        r->pcv.notify_all();
-        // the producer thread helps
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        inflateInit2(&zs, -15);
-        run_tasks(r, &zs);
-        inflateEnd(&zs);
-        {
-            std::unique_lock<std::mutex> lk(r->pmu);
-            r->dcv.wait(lk, [&] { return r->done_tasks.load() >= r->tasks.size(); });
-        }
-        if (r->task_err.load()) return -1;
-    }
+    if (run_batch(r) < 0) return -1;
     return (long long)produced;
+}
+
+// runs r->tasks on the worker pool (the calling producer thread helps); <0 on failure
+static long long run_batch(hhgt_reader *r)
+{
+    if (r->tasks.empty()) return 0;
+    r->done_tasks.store(0);
+    {
+        std::lock_guard<std::mutex> lk(r->pmu);
+        r->batch_id++;
+        r->open_gen.store(r->batch_id);
+        r->n_tasks.store(r->tasks.size());
+        r->ticket.store(r->batch_id << 32);
+    }
+    r->pcv.notify_all();
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    inflateInit2(&zs, -15);
+    run_tasks(r, &zs);
+    inflateEnd(&zs);
+    {
+        std::unique_lock<std::mutex> lk(r->pmu);
+        r->dcv.wait(lk, [&] { return r->done_tasks.load() >= r->tasks.size(); });
+    }
+    return r->task_err.load() ? -1 : 0;
 }
 
 static void producer_main(hhgt_reader *r)
@@ -334,10 +361,11 @@ extern "C" int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_th
         b.buf = static_cast<uint8_t *>(p);
     }
     for (int i = 0; i < n_blocks; ++i) r->free_.push_back(i);
-    if (r->is_bgzf) {
+    if (r->is_bgzf || !r->is_gzip) {
         unsigned hw = std::thread::hardware_concurrency();
         int nt = n_threads > 0 ? n_threads : (hw ? (int)hw : 4);
         if (nt > 64) nt = 64;
+        if (!r->is_bgzf && nt > 16) nt = 16;  // plain copies saturate memory bandwidth with few threads
         for (int i = 0; i < nt - 1; ++i) r->workers.emplace_back(worker_main, r);
     }
     r->producer = std::thread(producer_main, r);

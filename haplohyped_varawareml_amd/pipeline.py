@@ -129,6 +129,14 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
     return fs
 
 
+def _pinned(ctx, nbytes):
+    buf = getattr(ctx, "_pinned_out", None)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
+        ctx._pinned_out = buf
+    return buf
+
+
 def _emit(ctx, stage, n_cols, col_bytes, chunk_nbytes, on_columns, compress, fmt, fs):
     lay = stage.layout
     # sample-padding rows of the completed columns must be zero before they are framed
@@ -139,7 +147,12 @@ def _emit(ctx, stage, n_cols, col_bytes, chunk_nbytes, on_columns, compress, fmt
     fs.raw_bytes += cols.numel()
     if compress:
         dst, off, total = ctx.compress(cols, chunk_nbytes, typesize=dev.DEFAULT_TYPESIZE, blocksize=min(lay.vc * 2, dev.DEFAULT_BLOCKSIZE), fmt=fmt)
-        framed = (dst[:total].cpu().numpy(), off.cpu().numpy().astype(np.uint64))
+        # framed bytes leave the device through a pinned staging buffer (pageable D2H runs at a fraction of
+        # the link rate); the numpy view handed to on_columns is valid during the callback only
+        host = _pinned(ctx, total)
+        host[:total].copy_(dst[:total], non_blocking=True)
+        offs = off.cpu().numpy().astype(np.uint64)      # synchronises: the copy above is complete
+        framed = (host[:total].numpy(), offs)
         fs.compressed_bytes += total
     if on_columns:
         on_columns(cols, n_cols, framed)
