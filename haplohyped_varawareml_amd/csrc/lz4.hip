@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
 }
 
 __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out, uint32_t no_run)
+                                                         uint32_t hashlog, uint8_t *__restrict__ out)
 {
     // PMC (profiles/r01_pmc_lz4_v4_sq_*.csv) puts this loop at ~0.75 scalar instructions per cycle per CU:
     // the CU's single scalar unit is the bound.  Hence: per-lane predicates are kept as 0 / ~0 integers in
@@ -245,7 +245,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             // usable <=> pos <= mflimit, pos >= cur (and for (a): hcand < pos); >= 4 bytes equal
             const uint32_t out_of_range = ((mflimit - pos) >> 31) | ((pos - cur) >> 31);
             const uint32_t bad_h = xh[0] | out_of_range | ((pos - hcand - 1u) >> 31);
-            const uint32_t bad_r = out_of_range | ((run - 4u) >> 31) | no_run;
+            const uint32_t bad_r = out_of_range | ((run - 4u) >> 31);
             const unsigned long long M = __ballot((bad_h == 0u) | (bad_r == 0u));
             if (M == 0ull) {
                 p += 64u;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(1024) void k_lz4_blocks(const uint8_t *__restrict__
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
         uint32_t cs = (algo & 255u) == 1u ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                                          : lz4_wave_compress_v4(in, neblock, tb, hashlog, out, (algo >> 8) & 1u);
+                                          : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
             cs = neblock;
@@ -530,10 +530,8 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    // HHGT_LZ4_ALGO: 4 = window-parallel encoder (default), 1 = the simple first version;
-    // HHGT_LZ4_RUN=0 drops the offset-1 run candidate (about 8 % faster, ratio 3.36 instead of 4.36 on genotypes)
-    static const uint32_t algo = (getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 4u) |
-                                 ((getenv("HHGT_LZ4_RUN") && atoi(getenv("HHGT_LZ4_RUN")) == 0) ? 256u : 0u);
+    // HHGT_LZ4_ALGO: 4 = window-parallel encoder (default), 1 = the simple first version (kept for A/B runs)
+    static const uint32_t algo = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 4u;
     const uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
     if (grid > 0x7fffffffull) {
