@@ -419,7 +419,11 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
 
 // grid = n_chunks * nblocks; block = 64 * nwaves (nwaves = typesize when blocks are split, else 1)
 // dynamic LDS: [data: nwaves * sstride + 16][tables: nwaves << (hashlog + 1)]
-__global__ __launch_bounds__(1024) void k_lz4_blocks(const uint8_t *__restrict__ src, uint32_t nblocks,
+// MW = minimum waves per SIMD the register allocator must leave room for (0: no constraint, workgroups of up
+// to 16 waves for typesize 16).  The common genotype case (typesize 2 -> 2-wave workgroups) is latency bound,
+// so it is compiled for 8 resident waves per SIMD (<= 64 VGPRs).
+template <int MW, int ALGO>
+__global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(const uint8_t *__restrict__ src, uint32_t nblocks,
                                                      uint64_t chunk_nbytes, uint32_t typesize, uint32_t blocksize,
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
@@ -478,8 +482,9 @@ __global__ __launch_bounds__(1024) void k_lz4_blocks(const uint8_t *__restrict__
         const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
-        uint32_t cs = (algo & 255u) == 1u ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                                          : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
+        uint32_t cs = ALGO == 1 ? lz4_wave_compress(in, neblock, tb, hashlog, out)
+                                : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
+        (void)algo;
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
             cs = neblock;
@@ -526,8 +531,10 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     }
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in
     if (lds > attr_lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lz4_blocks),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1>), reinterpret_cast<const void *>(k_lz4_blocks<0, 4>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<6, 4>), reinterpret_cast<const void *>(k_lz4_blocks<7, 4>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<8, 4>)};
+        for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     // HHGT_LZ4_ALGO: 4 = window-parallel encoder (default), 1 = the simple first version (kept for A/B runs)
@@ -538,9 +545,18 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
         hhgt_set_error("lz4: too many blocks");
         return HHGT_ERR_ARG;
     }
-    hipLaunchKernelGGL(k_lz4_blocks, dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,
-                       chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch,
-                       (uint64_t)slot_bytes, d_csize);
+    static const int mw_env = getenv("HHGT_LZ4_MINWAVES") ? atoi(getenv("HHGT_LZ4_MINWAVES")) : 7;
+    const int mw = nwaves <= 2 ? mw_env : 0;
+#define LZ_LAUNCH(MWV, ALG)                                                                                          \
+    hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
+                       chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
+                       (uint64_t)slot_bytes, d_csize)
+    if (algo == 1u) LZ_LAUNCH(0, 1);
+    else if (mw == 8) LZ_LAUNCH(8, 4);
+    else if (mw == 7) LZ_LAUNCH(7, 4);
+    else if (mw == 6) LZ_LAUNCH(6, 4);
+    else LZ_LAUNCH(0, 4);
+#undef LZ_LAUNCH
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
