@@ -22,7 +22,7 @@ extern "C" {
 typedef struct hhgt_reader hhgt_reader;
 
 /* path: .vcf, .vcf.gz (gzip or BGZF).  block_bytes: size of each pinned block (>= 1 MiB; lines longer
- * than a block are an error).  n_threads: BGZF inflate workers (0 = hardware concurrency, max 64).
+ * than a block are an error).  n_threads: BGZF inflate workers (0 = hardware concurrency, max 192).
  * n_blocks: ring depth (>= 2; 0 = 3). */
 int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_threads, int n_blocks, hhgt_reader **out);
 void hhgt_reader_close(hhgt_reader *r);
