@@ -6,11 +6,12 @@
 // (and htslib's vcf_parse_format GT tokeniser behind it) by ONE pass over the sample columns of all
 // kept lines that emits every sample at once as G[s, v', 2].
 //
-// k_encode_tiles (fixed-width lines "a|b\t" x S — the 1000G shape): a 256-thread workgroup owns a
-//   128-variant x 256-sample tile.  Wave w reads 32 lines; lane l reads 16 contiguous bytes (4 samples)
-//   of each line, so every wave-load is a coalesced 1 KiB run of raw GT bytes.  Each lane packs its
-//   4 samples x 32 variants in registers, the tile is transposed through a 64 KiB XOR-swizzled LDS
-//   image (conflict-free ds_write_b128 / ds_read_b128) and leaves as 256-byte sample-row segments.
+// k_encode_tiles<TV> (fixed-width lines "a|b\t" x S — the 1000G shape): a 256-thread workgroup owns a
+//   TV-variant x 256-sample tile (TV = 64 by default: 32 KiB of LDS, four workgroups per CU).  Wave w reads
+//   TV/4 lines; lane l reads 16 contiguous bytes (4 samples) of each line, so every wave-load is a coalesced
+//   1 KiB run of raw GT bytes.  Each lane packs its 4 samples x TV/4 variants in registers, the tile is
+//   transposed through an XOR-swizzled LDS image (conflict-free ds_write_b128 / ds_read_b128) and leaves as
+//   2*TV-byte sample-row segments.
 //   HBM roofline: algorithmic bytes per variant = 4*S read + 2*S written; no MFMA (byte work).
 // k_encode_general (anything else: GT:DP columns, multi-digit alleles, haploid calls ...): one wave
 //   per line, tab-rank by ballot/prefix over 1 KiB pieces, htslib GT rule per field.

@@ -10,10 +10,14 @@
 // Workgroup = one block; wave j = stream j (byte plane j of the shuffled block when split).
 //   phase A  all waves: coalesced 16 B/lane loads of the block, byte-plane de-interleave in registers
 //            (v_perm_b32 for typesize 2), planes stored to LDS  -> shuffle costs no extra HBM traffic
-//   phase B  wave j: greedy LZ4 over its plane in LDS.  64 positions are hashed/looked up/verified per
-//            step (one position per lane), the first verified match is extended cooperatively
-//            (64 bytes per ballot), sequences are emitted with lane-parallel byte stores.
-// HBM roofline: algorithmic bytes = blocksize read + compressed bytes written (per block).
+//   phase B  wave j: greedy LZ4 over its plane in LDS, 64 positions (one per lane) per step
+//            (lz4_wave_compress_v4): every lane verifies and measures its own candidates — the hash table's
+//            most recent occurrence and the offset-1 run — from registers; the greedy left-to-right choice of
+//            non-overlapping matches is the only serial part and runs on the scalar unit; all sequences of
+//            the window are laid out with a DPP prefix sum and written by their own lanes.
+//            lz4_wave_compress (v1: one match per round trip) is kept as a second instantiation for A/B runs.
+// Algorithmic bytes = blocksize read + compressed bytes written per block; measured: the kernel is bound by
+// instruction issue, not by HBM.
 #include "common.h"
 #include <stdlib.h>
 
