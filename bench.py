@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--vc", type=int, default=dev.DEFAULT_VC, help="variants per chunk (chunk = 64 x vc x 2 bytes)")
     ap.add_argument("--blocksize", type=int, default=dev.DEFAULT_BLOCKSIZE, help="Blosc2 block bytes")
+    ap.add_argument("--clevel", type=int, default=5, help="codec level (reference: 5); 1-2 = run-only fast mode")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encode/compress overlap")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one GPU in rehearsals")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,6 +166,7 @@ def main():
             dist.init_process_group(args.dist_backend)
     torch.cuda.set_device(local_rank)
     ctx = dev.Context(local_rank)
+    ctx.set_clevel(args.clevel)
     S = args.samples
     shards = build_shards(ctx, args, rank, world)
     my_variants = sum(sh.V for sh in shards)
@@ -239,7 +241,7 @@ def main():
         "config": {"workload": f"1000G-style {args.variants} variants x {S} samples, 22 per-chromosome shards "
                                f"(BASELINE configs[2]), biallelic phased GT-only text resident in HBM",
                    "variants_per_gpu": my_variants, "samples": S, "text_bytes_per_gpu": text_bytes,
-                   "chunk": f"64 samples x {args.vc} variants x 2 int8, Blosc2 block {args.blocksize} B, typesize 2 (byte-shuffle), LZ4",
+                   "chunk": f"64 samples x {args.vc} variants x 2 int8, Blosc2 block {args.blocksize} B, typesize 2 (byte-shuffle), LZ4 clevel {args.clevel}",
                    "compression_ratio": g_bytes / max(comp_bytes, 1),
                    "parallelism": f"per-chromosome shards x{world}, no collective",
                    "streams": 1 if args.no_overlap else 2},

@@ -518,7 +518,7 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
         TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize,
-                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), st));
+                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel <= 2 ? 1 : 0, st));
         t.stop();
     }
     {
@@ -540,6 +540,16 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
             return HHGT_ERR_CAPACITY;
         }
     }
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)
+{
+    if (!c || clevel < 1 || clevel > 9) {
+        hhgt_set_error("clevel must be 1..9");
+        return HHGT_ERR_ARG;
+    }
+    c->clevel = clevel;
     return HHGT_OK;
 }
 

@@ -96,6 +96,7 @@ struct hhgt_ctx {
     // last encode's chrom runs (host)
     std::vector<uint64_t> run_first_kept;
     std::vector<std::string> run_names;
+    int clevel = 5;        // Blosc clevel analogue (reference: compression_opts[4] = 5)
     // profiling
     int profiling = 0;
     double stage_ms[HHGT_N_STAGES] = {0};
@@ -151,7 +152,7 @@ int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t
 // lz4.hip
 size_t lz4_slot_bytes(int neblock);
 int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int fast,
                       hipStream_t st);
 // frame.hip
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src,

@@ -195,6 +195,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
     return x;
 }
 
+// FAST = run candidate only (no hash table, no LDS gathers): the low-clevel mode, like LZ4's acceleration.
+template <bool FAST>
 __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint32_t n, uint16_t *tab,
                                                          uint32_t hashlog, uint8_t *__restrict__ out)
 {
@@ -223,11 +225,15 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
 #pragma unroll
             for (int k = 0; k < 5; ++k) o[k] = __builtin_amdgcn_alignbyte(own.w[k + 1], own.w[k], sh);
             const uint32_t d = o[0];
-            const uint32_t h = (d * 2654435761u) >> hshift;
-            const uint32_t hcand = (uint32_t)tab[h];
-            tab[pos <= mflimit ? h : dummy_slot] = (uint16_t)pos;
-            const Own6 cw = lds_load6(in, hcand);
-            const uint32_t hsh = hcand & 3u;
+            uint32_t hcand = 0u, hsh = 0u;
+            Own6 cw;
+            if constexpr (!FAST) {
+                const uint32_t h = (d * 2654435761u) >> hshift;
+                hcand = (uint32_t)tab[h];
+                tab[pos <= mflimit ? h : dummy_slot] = (uint16_t)pos;
+                cw = lds_load6(in, hcand);
+                hsh = hcand & 3u;
+            }
             // two candidates per position: (a) the hash table's most recent occurrence of these 4 bytes,
             // (b) offset 1 — the position continues a run of one byte value.  (b) needs no table and no LDS:
             // E = ballot(byte[pos] == byte[pos-1]) is one compare per window, and a lane's run length is the
@@ -243,9 +249,11 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const uint32_t r_lo = ~(lane < 32u ? __builtin_amdgcn_alignbit(E_hi, E_lo, lane) : E_hi >> (lane - 32u));
             const uint32_t r_hi = ~(lane < 32u ? E_hi >> lane : 0u);
             const uint32_t run = r_lo ? (uint32_t)__ffs((int)r_lo) - 1u : 31u + (uint32_t)__ffs((int)r_hi);  // <= 64 - lane
-            uint32_t xh[5];
+            uint32_t xh[5] = {1u, 1u, 1u, 1u, 1u};
+            if constexpr (!FAST) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) xh[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], hsh);
+                for (int k = 0; k < 5; ++k) xh[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], hsh);
+            }
             // usable <=> pos <= mflimit, pos >= cur (and for (a): hcand < pos); >= 4 bytes equal
             const uint32_t out_of_range = ((mflimit - pos) >> 31) | ((pos - cur) >> 31);
             const uint32_t bad_h = xh[0] | out_of_range | ((pos - hcand - 1u) >> 31);
@@ -271,7 +279,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             uint32_t len = use_run ? lenr : lenh;
             const uint32_t cand = use_run ? pos - 1u : hcand;
             const uint32_t csh = cand & 3u;
-            if (__ballot(am != 0u && !use_run) != 0ull) {  // second batch: bytes 20..35 of hash matches
+            if (!FAST && __ballot(am != 0u && !use_run) != 0ull) {  // second batch: bytes 20..35 of hash matches
                 const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
                 uint32_t amx = use_run ? 0u : am;
 #pragma unroll
@@ -486,8 +494,9 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
         const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
-        uint32_t cs = ALGO == 1 ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                                : lz4_wave_compress_v4(in, neblock, tb, hashlog, out);
+        uint32_t cs = ALGO == 1   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
+                      : ALGO == 5 ? lz4_wave_compress_v4<true>(in, neblock, tb, hashlog, out)
+                                  : lz4_wave_compress_v4<false>(in, neblock, tb, hashlog, out);
         (void)algo;
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
 }
 
 int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int fast,
                       hipStream_t st)
 {
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
@@ -536,6 +545,7 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in
     if (lds > attr_lds) {
         const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1>), reinterpret_cast<const void *>(k_lz4_blocks<0, 4>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<0, 5>), reinterpret_cast<const void *>(k_lz4_blocks<8, 5>),
                              reinterpret_cast<const void *>(k_lz4_blocks<6, 4>), reinterpret_cast<const void *>(k_lz4_blocks<7, 4>),
                              reinterpret_cast<const void *>(k_lz4_blocks<8, 4>)};
         for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -556,6 +566,8 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
                        (uint64_t)slot_bytes, d_csize)
     if (algo == 1u) LZ_LAUNCH(0, 1);
+    else if (fast && nwaves <= 2) LZ_LAUNCH(8, 5);
+    else if (fast) LZ_LAUNCH(0, 5);
     else if (mw == 8) LZ_LAUNCH(8, 4);
     else if (mw == 7) LZ_LAUNCH(7, 4);
     else if (mw == 6) LZ_LAUNCH(6, 4);

@@ -138,6 +138,10 @@ class Context:
             check(self.lib.hhgt_pad_tail(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end),
                                          _ptr(res.G), _stream()))
 
+    def set_clevel(self, clevel):
+        """Blosc clevel analogue: 3..9 (default 5, the reference's setting) full matcher; 1..2 run-only"""
+        check(self.lib.hhgt_set_clevel(self.h, int(clevel)))
+
     # ---- codec ---------------------------------------------------------------------------------
     def compress(self, src, chunk_nbytes, typesize=DEFAULT_TYPESIZE, blocksize=None, fmt=BLOSC2,
                  dst=None, chunk_off=None, sync=True):

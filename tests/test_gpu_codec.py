@@ -121,3 +121,22 @@ def test_fixture_chunk_matches_oracle_decode(ctx, golden_dir):
     import os
     G = np.load(os.path.join(golden_dir, "fixture_G.npy"))
     roundtrip(ctx, G.reshape(-1).view(np.uint8).copy(), 6000, 2, 2000, dev.BLOSC2)
+
+
+def test_clevel_fast_mode_roundtrip(ctx):
+    """clevel 1-2 = run candidate only (LZ4 'acceleration'); still a valid stream for every decoder"""
+    from haplohyped_varawareml_amd._lib import HhgtError
+    G = genotype_like(64 * 2, 8192, 13)
+    data = np.ascontiguousarray(G.reshape(2, 64, 8192, 2)).reshape(-1).view(np.uint8)
+    try:
+        ctx.set_clevel(1)
+        fast = roundtrip(ctx, data, 64 * 8192 * 2, 2, 8192, dev.BLOSC1)
+        for name, arr in cases():
+            if arr.size >= 64:
+                roundtrip(ctx, arr, arr.size, 1, min(arr.size, 65536), dev.BLOSC2)
+    finally:
+        ctx.set_clevel(5)
+    full = roundtrip(ctx, data, 64 * 8192 * 2, 2, 8192, dev.BLOSC1)
+    assert sum(c.size for c in full) < sum(c.size for c in fast) < data.size / 2
+    with pytest.raises(HhgtError):
+        ctx.set_clevel(0)
