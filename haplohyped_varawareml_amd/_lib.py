@@ -79,6 +79,7 @@ def load():
     L.hhgt_compress_chunks.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, u64, vp, C.POINTER(u64), vp]
     L.hhgt_decompress_chunks.argtypes = [vp, vp, vp, u64, u64, i32, i32, vp, C.POINTER(u64), vp]
     L.hhgt_onehot_windows.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, i32, vp, vp, vp]
+    L.hhgt_onehot_bases_u8.argtypes = [vp, vp, u64, vp, i32, vp, vp]
     L.hhgt_profile_enable.argtypes = [vp, i32]
     L.hhgt_profile_reset.argtypes = [vp]
     L.hhgt_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]

@@ -124,3 +124,62 @@ extern "C" int hhgt_onehot_windows(hhgt_ctx *c, const hhgt_window *d_items, uint
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// bases -> uint8 one-hot rows [n][C] (reference genome store).  One thread = 4 output bytes.
+__global__ __launch_bounds__(256) void k_onehot_bases_u8(const uint8_t *__restrict__ bases, uint64_t n, uint32_t C,
+                                                         OneHotLut lut, uint8_t *__restrict__ out)
+{
+    const uint64_t total = n * C;
+    const uint64_t nq = (total + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e0 = 4 * q;
+        uint64_t i = e0 / C;
+        uint32_t c = (uint32_t)(e0 - i * C);
+        uint32_t ch = 256, word = 0;
+        uint64_t cur_i = ~0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k < total) {
+                if (i != cur_i) {
+                    ch = lut.v[bases[i]];
+                    cur_i = i;
+                }
+                word |= (c == ch ? 1u : 0u) << (8 * k);
+            }
+            if (++c == C) {
+                c = 0;
+                ++i;
+            }
+        }
+        if (e0 + 4 <= total) *reinterpret_cast<uint32_t *>(out + e0) = word;
+        else
+            for (int k = 0; k < 4; ++k)
+                if (e0 + k < total) out[e0 + k] = (uint8_t)(word >> (8 * k));
+    }
+}
+
+extern "C" int hhgt_onehot_bases_u8(hhgt_ctx *c, const uint8_t *d_bases, uint64_t n, const uint8_t *lut, int n_channels,
+                                    uint8_t *d_out, void *stream)
+{
+    if (!c || !d_bases || !lut || !d_out || n_channels < 1 || n_channels > 254) {
+        hhgt_set_error("onehot_bases: bad arguments");
+        return HHGT_ERR_ARG;
+    }
+    if (n == 0) return HHGT_OK;
+    if (reinterpret_cast<uintptr_t>(d_out) & 3u) {
+        hhgt_set_error("onehot_bases: d_out must be 4-byte aligned");
+        return HHGT_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    OneHotLut L;
+    for (int i = 0; i < 256; ++i) L.v[i] = lut[i] < (uint8_t)n_channels ? lut[i] : (uint8_t)255;
+    const uint64_t nq = (n * (uint64_t)n_channels + 3) / 4;
+    uint32_t gx = (uint32_t)((nq + 255) / 256 < 65536 ? (nq + 255) / 256 : 65536);
+    StageTimer t(c, reinterpret_cast<hipStream_t>(stream), HHGT_STAGE_ONEHOT);
+    hipLaunchKernelGGL(k_onehot_bases_u8, dim3(gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_bases, n,
+                       (uint32_t)n_channels, L, d_out);
+    t.stop();
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}

@@ -22,6 +22,7 @@ There are no reference outputs to pin this consumer to ("parity unpinned"); test
 tensors with a numpy restatement of the rules above.
 """
 import ctypes as C
+import json
 import os
 from collections import OrderedDict
 
@@ -83,9 +84,16 @@ def read_fasta(path):
 class ReferenceGenome:
     """haplotype_dataset.py:18-28 — `get_sequence(chrom, start, end)` returns |S1 bases"""
 
-    def __init__(self, path, encode_spec=None, device=None):
+    def __init__(self, path, encode_spec=None, device=None, ctx=None):
         self.encode_spec = parse_encode_dict(encode_spec)
-        if str(path).endswith(".npz"):
+        self._store = None
+        if os.path.isdir(str(path)):
+            # the one-hot reference store written by fasta_encoder (fasta_encoder.py's reference_genome.h5)
+            from .fasta_encoder import ReferenceGenome as EncodedGenome
+            self._store = EncodedGenome(hdf5_file=str(path), ctx=ctx)
+            meta = json.load(open(os.path.join(str(path), "meta.json")))
+            self.contigs = {c: None for c in meta["contigs"]}
+        elif str(path).endswith(".npz"):
             z = np.load(path)
             self.contigs = {k: z[k] for k in z.files}
         else:
@@ -94,12 +102,24 @@ class ReferenceGenome:
         self._dev = {}
 
     def get_sequence(self, chrom, start, end):
-        return self.contigs[str(chrom)][start:end].view("|S1")
+        return self.host_bases(str(chrom))[start:end].view("|S1")
 
     def device_bases(self, chrom):
         if chrom not in self._dev:
-            self._dev[chrom] = torch.from_numpy(self.contigs[chrom]).to(self.device)
+            if self._store is not None:
+                # one-hot rows -> base letters, on the device (columns are in the store's sorted order)
+                m = self._store.contig_meta(chrom)
+                rows = self._store.get_sequence_device(chrom, 0, m["length"])
+                letters = torch.tensor([ord(c) for c in m["columns"]], dtype=torch.uint8, device=rows.device)
+                self._dev[chrom] = letters[rows.argmax(dim=1)].contiguous()
+            else:
+                self._dev[chrom] = torch.from_numpy(self.contigs[chrom]).to(self.device)
         return self._dev[chrom]
+
+    def host_bases(self, chrom):
+        if self._store is not None:
+            return self.device_bases(chrom).cpu().numpy()
+        return self.contigs[chrom]
 
     def close(self):
         self._dev.clear()
@@ -118,7 +138,7 @@ class RandomHaplotypeDataset(Dataset):
         self._own_ctx = ctx is None
         self.ctx = ctx or Context(0)
         self.store = GenotypeStore(hdf5_genotype_file, ctx=self.ctx)
-        self.reference_genome = ReferenceGenome(hdf5_reference_file, encode_spec, device=self.ctx.device)
+        self.reference_genome = ReferenceGenome(hdf5_reference_file, encode_spec, device=self.ctx.device, ctx=self.ctx)
         self.encode_spec = parse_encode_dict(encode_spec)
         self.lut, self.n_channels = channel_lut(encode_spec)
         self.donor_ids = self.read_samples(samples_file)

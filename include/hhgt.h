@@ -173,6 +173,13 @@ typedef struct {
 int hhgt_onehot_windows(hhgt_ctx *ctx, const hhgt_window *d_items, uint32_t n_items, uint32_t seq_len,
                         const uint8_t *lut, int n_channels, float *d_hap1, float *d_hap2, void *stream);
 
+/* One-hot of a base string for the reference-genome store: replaces
+ * ReferenceGenome.array_to_onehot / encode_sequence, /root/reference/src/haplohyped/fasta_encoder.py:47-78
+ * (upper-case, non-ACGT -> N, one uint8 column per base, columns in sorted order A,C,G,N,T there).
+ * d_out: uint8 [n][n_channels]; lut as in hhgt_onehot_windows. */
+int hhgt_onehot_bases_u8(hhgt_ctx *ctx, const uint8_t *d_bases, uint64_t n, const uint8_t *lut, int n_channels,
+                         uint8_t *d_out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-stage device timing (HIP events on the launch stream).  Stages are indexed by HHGT_STAGE_*.
  * hhgt_profile_read returns accumulated milliseconds and launch counts since the last reset.

@@ -36,7 +36,7 @@ def numpy_expected(ds, items):
     out2 = np.zeros_like(out1)
     for b, it in enumerate(items):
         seq = np.full(L, ord("N"), np.uint8)
-        ref = ds.reference_genome.contigs.get(it["chrom"])
+        ref = ds.reference_genome.host_bases(it["chrom"]) if it["chrom"] in ds.reference_genome.contigs else None
         if ref is not None:
             a, e = it["start"], min(it["start"] + L, len(ref))
             if e > a:
@@ -113,4 +113,38 @@ def test_dataset_config5_shape(ctx, tmp_path, golden_dir):
     e1, e2 = numpy_expected(ds, ds.last_items[:2])
     assert np.array_equal(h1[:2].cpu().numpy(), e1) and np.array_equal(h2[:2].cpu().numpy(), e2)
     assert sum(it["var_hi"] - it["var_lo"] for it in ds.last_items) > 32     # windows do contain variants
+    ds.close()
+
+
+@pytest.mark.gpu
+def test_dataset_reads_fasta_encoder_store(ctx, tmp_path, golden_dir):
+    """full chain of the reference's README: vcf_to_h5 + fasta_encoder -> RandomHaplotypeDataset"""
+    import shutil
+    from click.testing import CliRunner
+    from haplohyped_varawareml_amd import fasta_encoder
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    from haplohyped_varawareml_amd.dataset import RandomHaplotypeDataset
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr22.filtered.vcf.gz"), vcf_dir / "chr22.filtered.vcf.gz")
+    samples = os.path.join(golden_dir, "ipscs_samples_test.txt")
+    store = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "out"), samples, 2, 1).run()
+    rng = np.random.default_rng(7)
+    seq = b"".join(rng.choice([b"A", b"C", b"G", b"T", b"N", b"g"], 20_050_000).tolist())
+    fa = tmp_path / "ref.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chr22\n")
+        for i in range(0, len(seq), 60):
+            f.write(seq[i:i + 60] + b"\n")
+    res = CliRunner().invoke(fasta_encoder.main, ["--fasta", str(fa), "--outdir", str(tmp_path / "out"), "--cores", "2"])
+    assert res.exit_code == 0, res.output
+    ref_store = str(tmp_path / "out" / "reference_genome.hhgt")
+    ds = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), store, ref_store, samples, seed=1,
+                                batch_size=4, seq_length=2000, ctx=ctx)
+    h1, h2 = ds[0]
+    # the store keeps upper-cased bases with non-ACGT folded to N, exactly what the one-hot rule sees
+    e1, e2 = numpy_expected(ds, ds.last_items)
+    assert np.array_equal(h1.cpu().numpy(), e1) and np.array_equal(h2.cpu().numpy(), e2)
+    up = np.frombuffer(seq.upper(), dtype=np.uint8)
+    assert np.array_equal(ds.reference_genome.host_bases("chr22"), up)
     ds.close()
