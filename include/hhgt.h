@@ -126,7 +126,10 @@ int hhgt_pad_tail(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_
  *   d_dst        : receives the framed chunks back to back; chunk i occupies
  *                  [d_chunk_off[i], d_chunk_off[i+1])
  *   d_chunk_off  : device array of n_chunks + 1 uint64
- *   total_bytes  : host, optional; when non-NULL the call synchronises and returns the total
+ *   total_bytes  : host, optional; when non-NULL the call synchronises and returns the total (and
+ *                  HHGT_ERR_CAPACITY if it exceeds dst_cap).  When NULL the call is asynchronous: chunks that would
+ *                  not fit are not written, and the caller must check d_chunk_off[n_chunks] <= dst_cap itself
+ *                  (dst_cap >= hhgt_compress_bound(...) always fits).
  * Constraints: 1 <= typesize <= 255; blocksize % typesize == 0; 16 <= blocksize <= 65536 (clamped to the chunk size, as c-blosc does);
  * chunk_nbytes < 2 GiB.
  * ------------------------------------------------------------------------------------------- */
