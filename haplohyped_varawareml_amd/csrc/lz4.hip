@@ -361,53 +361,55 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const uint32_t prev_end_raw = (uint32_t)__shfl((int)endp, (int)prev, 64);
             const uint32_t anc = (b_lo | b_hi) ? prev_end_raw : anchor;  // end of the previous selected match
             const uint32_t ll = pos - anc, mlc = len - LZ_MINMATCH;       // meaningful on selected lanes
-            const uint32_t llx = ll >= 15u ? div255(ll - 15u) + 1u : 0u;
-            const uint32_t mlx = mlc >= 15u ? div255(mlc - 15u) + 1u : 0u;
+            // extension bytes: only the FIRST sequence of a window can carry more than 63 literals and only the
+            // LAST match can be longer than the 36-byte cap, so every other lane needs at most one extension
+            // byte (ll - 15 < 255, mlc - 15 < 255); the two special lanes get their counts from scalar code
+            const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
+            const uint32_t ll_first = p + first - anchor, ml_last = lcur - last - LZ_MINMATCH;
+            const uint32_t llx_first = ll_first >= 15u ? div255(ll_first - 15u) + 1u : 0u;
+            const uint32_t mlx_last = ml_last >= 15u ? div255(ml_last - 15u) + 1u : 0u;
+            const uint32_t llx = lane == first ? llx_first : (ll >= 15u ? 1u : 0u);
+            const uint32_t mlx = lane == last ? mlx_last : (mlc >= 15u ? 1u : 0u);
             const uint32_t size = (3u + llx + ll + mlx) & selm;
             uint32_t total;
             const uint32_t so = wave_incl_scan_dpp(size, lane, &total) - size;
             // literals: lanes not covered by a selected match that have a selected match above them
             const uint32_t a_lo = sel_lo & above_lo, a_hi = sel_hi & above_hi;
             const uint32_t nxt = a_lo ? (uint32_t)__ffs((int)a_lo) - 1u : (a_hi ? 31u + (uint32_t)__ffs((int)a_hi) : lane);
-            const int base = (int)(so + 1u + llx) - (int)anc;   // on selected lanes: literal area base - anchor
-            const int bn = __shfl(base, (int)nxt, 64);
-            uint8_t *const wout = out + op;
+            const uint32_t base = op + so + 1u + llx - anc;   // on selected lanes: out offset of input byte `anc`... + pos
+            const uint32_t bn = (uint32_t)__shfl((int)base, (int)nxt, 64);
+            const uint32_t oq = op + so;                      // all stores: uniform `out` + 32-bit lane offset
             if (selm) {
                 // token, then (same lane, program order) the optional one-byte extensions; a lane without an
                 // extension re-writes its own token / high offset byte instead of branching
-                uint8_t *oq = wout + so;
                 const uint32_t token = ((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u);
-                const uint32_t q = 1u + llx + ll;
+                const uint32_t q = oq + 1u + llx + ll;
                 const uint32_t off = pos - cand;
-                oq[0] = (uint8_t)token;
-                oq[llx == 1u ? 1u : 0u] = (uint8_t)(llx == 1u ? ll - 15u : token);
-                oq[q] = (uint8_t)(off & 0xFFu);
-                oq[q + 1u] = (uint8_t)(off >> 8);
-                oq[mlx == 1u ? q + 2u : q + 1u] = (uint8_t)(mlx == 1u ? mlc - 15u : off >> 8);
+                out[oq] = (uint8_t)token;
+                out[oq + (llx == 1u ? 1u : 0u)] = (uint8_t)(llx == 1u ? ll - 15u : token);
+                out[q] = (uint8_t)(off & 0xFFu);
+                out[q + 1u] = (uint8_t)(off >> 8);
+                out[q + (mlx == 1u ? 2u : 1u)] = (uint8_t)(mlx == 1u ? mlc - 15u : off >> 8);
             } else if ((a_lo | a_hi) && pos >= anc) {
                 // not selected, something selected above, not inside the previous selected match
-                wout[bn + (int)pos] = (uint8_t)(d & 0xFFu);
+                out[bn + pos] = (uint8_t)(d & 0xFFu);
             }
-            if (__ballot((llx | mlx) > 1u) != 0ull) {  // rare: 255-runs (long literal runs / long matches)
+            if ((llx_first | mlx_last) > 1u) {  // rare: 255-runs (long literal run in front / long last match)
                 if (selm && (llx | mlx) > 1u) {
-                    uint8_t *oq = wout + so;
-                    const uint32_t q = 1u + llx + ll;
+                    const uint32_t q = oq + 1u + llx + ll;
                     if (llx > 1u) {
                         const uint32_t rem = ll - 15u;
-                        for (uint32_t k = 0; k < llx; ++k) oq[1u + k] = (k == llx - 1u) ? (uint8_t)(rem - 255u * (llx - 1u)) : (uint8_t)255u;
+                        for (uint32_t k = 0; k < llx; ++k) out[oq + 1u + k] = (k == llx - 1u) ? (uint8_t)(rem - 255u * (llx - 1u)) : (uint8_t)255u;
                     }
                     if (mlx > 1u) {
                         const uint32_t rem = mlc - 15u;
-                        for (uint32_t k = 0; k < mlx; ++k) oq[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem - 255u * (mlx - 1u)) : (uint8_t)255u;
+                        for (uint32_t k = 0; k < mlx; ++k) out[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem - 255u * (mlx - 1u)) : (uint8_t)255u;
                     }
                 }
             }
             // literals of the first sequence that lie in front of this window (pending from earlier windows)
             if (anchor < p) {
-                const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
-                const uint32_t ll0 = p + first - anchor;
-                const uint32_t llx0 = ll0 >= 15u ? div255(ll0 - 15u) + 1u : 0u;
-                const uint32_t dst0 = op + 1u + llx0;
+                const uint32_t dst0 = op + 1u + llx_first;
                 const uint32_t npre = p - anchor;
                 for (uint32_t k = lane; k < npre; k += 64u) out[dst0 + k] = in[anchor + k];
             }
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // wave index through readfirstlane: everything derived from it (stream base, output slot) stays in SGPRs,
+    // so the byte stores below use the SGPR-base + 32-bit-offset addressing form
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint64_t chunk = blockIdx.x / nblocks;
     const uint32_t b = blockIdx.x - (uint32_t)(chunk * nblocks);
     const uint64_t boff = (uint64_t)b * blocksize;
