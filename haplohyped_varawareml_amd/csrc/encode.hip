@@ -185,13 +185,13 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 
 // -------------------------------------------------------------------------------------------------
 // htslib vcf_parse_format GT rule (see oracle/vcf_oracle.c parse_gt for the restatement it mirrors)
-__device__ __forceinline__ uint32_t parse_gt_bytes(const uint8_t *__restrict__ text, uint32_t p, uint32_t lim,
-                                                   uint32_t *n_alleles)
+template <typename RD>
+__device__ __forceinline__ uint32_t parse_gt_bytes(RD rd, uint32_t p, uint32_t lim, uint32_t *n_alleles)
 {
     int l = 0;
     int vals[2] = {-9, -9};
     for (;;) {
-        uint32_t c = p < lim ? text[p] : 0u;
+        uint32_t c = p < lim ? rd(p) : 0u;
         if (c == '.') {
             ++p;
             if (l < 2) vals[l] = -9;
@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t parse_gt_bytes(const uint8_t *__restrict__ t
         } else if (c - '0' < 10u) {
             long long v = 0;
             while (p < lim) {
-                uint32_t d = (uint32_t)text[p] - '0';
+                uint32_t d = rd(p) - '0';
                 if (d >= 10u) break;
                 v = v * 10 + d;
                 if (v > 0x7fffffffLL) v &= 0x7fffffffLL;
@@ -209,7 +209,7 @@ __device__ __forceinline__ uint32_t parse_gt_bytes(const uint8_t *__restrict__ t
             ++l;
         } else
             break;
-        c = p < lim ? text[p] : 0u;
+        c = p < lim ? rd(p) : 0u;
         if (c != '|' && c != '/') break;
         ++p;
     }
@@ -220,6 +220,8 @@ __device__ __forceinline__ uint32_t parse_gt_bytes(const uint8_t *__restrict__ t
     *n_alleles = (uint32_t)l;
     return ((uint32_t)vals[0] & 0xFFu) | (((uint32_t)vals[1] & 0xFFu) << 8);
 }
+
+#define GEN_HALO 64u  // bytes staged past each 1 KiB piece: a GT sub-field that starts in the piece ends inside it
 
 __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restrict__ text, uint64_t n,
                                                         const uint32_t *__restrict__ k_soff,
@@ -233,6 +235,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t n_redo = (uint32_t)cnt->n_general;
     const uint32_t S = lay.S;
+    // each wave stages the 1 KiB piece it is ranking (plus a halo) in LDS: the per-field byte walk then reads LDS
+    // instead of issuing one global load per character
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[4][1024 + GEN_HALO];
+    uint8_t *buf = sbuf[threadIdx.x >> 6];
     uint32_t haploid = 0, malformed = 0;
     for (uint32_t idx = wave; idx < n_redo; idx += n_waves) {
         const uint32_t k = redo_list[idx];
@@ -249,6 +255,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 // one unaligned 16-byte load + exact per-byte "== tab" mask (SWAR), 4 bits per dword
                 const u32x4_unaligned t4 = *reinterpret_cast<const u32x4_unaligned *>(text + b0);
                 const uint32_t wv[4] = {t4.x, t4.y, t4.z, t4.w};
+                *reinterpret_cast<uint4 *>(buf + 16u * lane) = make_uint4(t4.x, t4.y, t4.z, t4.w);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t t = wv[q] ^ 0x09090909u;
@@ -258,9 +265,28 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
             } else if (b0 < lend) {
                 for (uint32_t j = 0; j < 16u; ++j) {
                     uint32_t p = b0 + j;
-                    if (p < lend && text[p] == '\t') m |= 1u << j;
+                    if (p < lend) {
+                        const uint8_t ch = text[p];
+                        buf[16u * lane + j] = ch;
+                        if (ch == '\t') m |= 1u << j;
+                    }
                 }
             }
+            if (lane < GEN_HALO / 16u) {
+                const uint32_t hb = base + 1024u + 16u * lane;
+                if (hb + 16u <= lend) {
+                    const u32x4_unaligned h4 = *reinterpret_cast<const u32x4_unaligned *>(text + hb);
+                    *reinterpret_cast<uint4 *>(buf + 1024u + 16u * lane) = make_uint4(h4.x, h4.y, h4.z, h4.w);
+                } else {
+                    for (uint32_t j = 0; j < 16u; ++j)
+                        if (hb + j < lend) buf[1024u + 16u * lane + j] = text[hb + j];
+                }
+            }
+            const uint32_t avail = lend - base < 1024u + GEN_HALO ? lend - base : 1024u + GEN_HALO;
+            auto rd = [&](uint32_t p) -> uint32_t {
+                const uint32_t o = p - base;
+                return o < avail ? (uint32_t)buf[o] : (uint32_t)text[p];  // beyond the halo: rare long sub-fields
+            };
             uint32_t c = __popc(m), inc = c;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -276,8 +302,8 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 uint32_t p = b0 + (uint32_t)j + 1u;
                 bool missing = false;
                 for (uint32_t gsk = 0; gsk < gtidx; ++gsk) {  // skip to the GT sub-field
-                    while (p < lend && text[p] != ':' && text[p] != '\t') ++p;
-                    if (p < lend && text[p] == ':') ++p;
+                    while (p < lend && rd(p) != ':' && rd(p) != '\t') ++p;
+                    if (p < lend && rd(p) == ':') ++p;
                     else {
                         missing = true;
                         break;
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 uint32_t na = 1, hv = 0xF7F7u;
                 if (!missing) {
                     // the sub-field ends at ':' or at the column's tab; both stop the GT rule
-                    hv = parse_gt_bytes(text, p, lend, &na);
+                    hv = parse_gt_bytes(rd, p, lend, &na);
                 }
                 if (na == 1u) ++haploid;
                 const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
