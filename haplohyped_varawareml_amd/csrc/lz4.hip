@@ -196,9 +196,68 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
 }
 
 // FAST = run candidate only (no hash table, no LDS gathers): the low-clevel mode, like LZ4's acceleration.
+// Layout + emission of the queued sequences, one per lane (lane j = j-th match in stream order).
+// queue[j] = (pos | len << 16, offset).  Updates op (output size so far) and anchor (end of the last match).
+__device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__restrict__ out, const uint2 *queue,
+                                                uint32_t qn, uint32_t &op, uint32_t &anchor, uint32_t lane)
+{
+    const bool valid = lane < qn;
+    const uint2 e = valid ? queue[lane] : make_uint2(0u, 0u);
+    const uint32_t pos = e.x & 0xFFFFu, len = e.x >> 16, off = e.y;
+    const uint32_t endp = pos + len;
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)endp, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    const uint32_t prev_end = lane ? up : anchor;
+    const uint32_t ll = valid ? pos - prev_end : 0u, mlc = len - LZ_MINMATCH;
+    const uint32_t llx = ll >= 15u ? div255(ll - 15u) + 1u : 0u;
+    const uint32_t mlx = (valid && mlc >= 15u) ? div255(mlc - 15u) + 1u : 0u;
+    const uint32_t size = valid ? 3u + llx + ll + mlx : 0u;
+    uint32_t total;
+    const uint32_t so = op + wave_incl_scan_dpp(size, lane, &total) - size;
+    if (valid) {
+        const uint32_t token = ((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u);
+        const uint32_t q = so + 1u + llx + ll;
+        out[so] = (uint8_t)token;
+        out[so + (llx == 1u ? 1u : 0u)] = (uint8_t)(llx == 1u ? ll - 15u : token);
+        out[q] = (uint8_t)(off & 0xFFu);
+        out[q + 1u] = (uint8_t)(off >> 8);
+        out[q + (mlx == 1u ? 2u : 1u)] = (uint8_t)(mlx == 1u ? mlc - 15u : off >> 8);
+    }
+    if (__ballot((llx | mlx) > 1u) != 0ull) {  // rare: 255-runs
+        if (valid && (llx | mlx) > 1u) {
+            const uint32_t q = so + 1u + llx + ll;
+            if (llx > 1u) {
+                const uint32_t rem = ll - 15u;
+                for (uint32_t k = 0; k < llx; ++k) out[so + 1u + k] = (k == llx - 1u) ? (uint8_t)(rem - 255u * (llx - 1u)) : (uint8_t)255u;
+            }
+            if (mlx > 1u) {
+                const uint32_t rem = mlc - 15u;
+                for (uint32_t k = 0; k < mlx; ++k) out[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem - 255u * (mlx - 1u)) : (uint8_t)255u;
+            }
+        }
+    }
+    // literals: short runs by their own lane, long runs (> 32 bytes: incompressible stretches) by the whole wave
+    const uint32_t lit_dst = so + 1u + llx;
+    unsigned long long big = __ballot(ll > 32u);
+    while (big) {
+        const uint32_t j = (uint32_t)__ffsll((long long)big) - 1u;
+        big &= big - 1ull;
+        const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane((int)ll, (int)j);
+        const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)prev_end, (int)j);
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)lit_dst, (int)j);
+        for (uint32_t k = lane; k < n_l; k += 64u) out[dst + k] = in[src + k];
+    }
+    const uint32_t lshort = ll > 32u ? 0u : ll;
+    for (uint32_t k = 0; __ballot(k < lshort) != 0ull; ++k)
+        if (k < lshort) out[lit_dst + k] = in[prev_end + k];
+    op += total;
+    anchor = (uint32_t)__builtin_amdgcn_readlane((int)endp, (int)(qn - 1u));
+}
+
+// v6: v4's search and parse (history: DESIGN.md §3.1) with deferred, batched emission (lz4_flush_queue).
+// FAST = run candidate only (no hash table, no LDS gathers): the low-clevel mode, like LZ4's acceleration.
 template <bool FAST>
-__device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint32_t n, uint16_t *tab,
-                                                         uint32_t hashlog, uint8_t *__restrict__ out)
+__device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint32_t n, uint16_t *tab,
+                                                         uint32_t hashlog, uint8_t *__restrict__ out, uint2 *queue)
 {
     // PMC (profiles/r01_pmc_lz4_v4_sq_*.csv) puts this loop at ~0.75 scalar instructions per cycle per CU:
     // the CU's single scalar unit is the bound.  Hence: per-lane predicates are kept as 0 / ~0 integers in
@@ -212,7 +271,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
     const uint32_t above_lo = lane >= 31u ? 0u : (0xFFFFFFFFu << (lane + 1u));
     const uint32_t above_hi = lane < 32u ? 0xFFFFFFFFu : (lane == 63u ? 0u : (0xFFFFFFFFu << (lane - 31u)));
     const uint32_t lane_bit_lo = lane < 32u ? 1u << lane : 0u, lane_bit_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
-    uint32_t op = 0, anchor = 0, cur = 0;
+    uint32_t op = 0, anchor = 0, cur = 0, qn = 0;
     if (n > LZ_MFLIMIT) {
         const uint32_t mflimit = n - LZ_MFLIMIT, matchlimit = n - LZ_LASTLITERALS;
         const uint32_t hshift = 32u - hashlog;
@@ -264,14 +323,11 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
                 own = lds_load6(in, p + lane);
                 continue;
             }
-            uint32_t amh = bad_h == 0u ? 0xFFFFFFFFu : 0u;
-            uint32_t lenh = 4u & amh;
-#pragma unroll
-            for (int k = 1; k < 5; ++k) {
-                const uint32_t nh = eq_bytes(xh[k]);
-                lenh += nh & amh;
-                amh &= 0u - (nh >> 2);
-            }
+            // equal bytes of xh[1..4]: the first non-zero dword decides (all four zero: 4 + 12 + 4 = 20, still matching)
+            const uint32_t t1 = xh[1] ? xh[1] : (xh[2] ? xh[2] : (xh[3] ? xh[3] : xh[4]));
+            const uint32_t skip = xh[1] ? 0u : (xh[2] ? 4u : (xh[3] ? 8u : 12u));
+            const uint32_t lenh = bad_h == 0u ? 4u + skip + eq_bytes(t1) : 0u;
+            uint32_t amh = (bad_h | xh[1] | xh[2] | xh[3] | xh[4]) == 0u ? 0xFFFFFFFFu : 0u;
             const uint32_t lenr = bad_r == 0u ? run : 0u;
             const bool use_run = lenr >= lenh;                      // ties go to the run (offset 1)
             // "still matching": a run that reaches the window end, or a hash match alive after 20 bytes
@@ -281,15 +337,15 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const uint32_t csh = cand & 3u;
             if (!FAST && __ballot(am != 0u && !use_run) != 0ull) {  // second batch: bytes 20..35 of hash matches
                 const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
-                uint32_t amx = use_run ? 0u : am;
+                uint32_t y[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t xx = __builtin_amdgcn_alignbyte(o2.w[k + 1], o2.w[k], sh) ^
-                                        __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], csh);
-                    const uint32_t nm = eq_bytes(xx);
-                    len += nm & amx;
-                    amx &= 0u - (nm >> 2);
-                }
+                for (int k = 0; k < 4; ++k)
+                    y[k] = __builtin_amdgcn_alignbyte(o2.w[k + 1], o2.w[k], sh) ^ __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], csh);
+                const uint32_t t2 = y[0] ? y[0] : (y[1] ? y[1] : (y[2] ? y[2] : y[3]));
+                const uint32_t skip2 = y[0] ? 0u : (y[1] ? 4u : (y[2] ? 8u : 12u));
+                const bool more = !use_run && am != 0u;
+                len += more ? skip2 + eq_bytes(t2) : 0u;
+                const uint32_t amx = (more && (y[0] | y[1] | y[2] | y[3]) == 0u) ? 0xFFFFFFFFu : 0u;
                 am = use_run ? am : amx;
             }
             const uint32_t maxlen = matchlimit - pos;
@@ -352,74 +408,23 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v4(const uint8_t *in, uint
             const uint32_t ncur = p + lcur;
             const uint32_t np = ncur > p + 64u ? ncur : p + 64u;
             const Own6 nown = lds_load6(in, np + lane);
-            // ---- layout, lane-parallel from SEL
+            // ---- enqueue the selected matches; layout + emission happen once per ~16 windows (flush), one
+            //      sequence per lane, instead of once per window with 4 of 64 lanes busy
             const uint32_t sel_lo = (uint32_t)SEL, sel_hi = (uint32_t)(SEL >> 32);
-            const uint32_t selm = ((sel_lo & lane_bit_lo) | (sel_hi & lane_bit_hi)) ? 0xFFFFFFFFu : 0u;
-            const uint32_t b_lo = sel_lo & below_lo, b_hi = sel_hi & below_hi;
-            const uint32_t prev = b_hi ? 63u - (uint32_t)__clz((int)b_hi) : 31u - (uint32_t)__clz((int)(b_lo | 1u));
-            const uint32_t endp = pos + len;
-            const uint32_t prev_end_raw = (uint32_t)__shfl((int)endp, (int)prev, 64);
-            const uint32_t anc = (b_lo | b_hi) ? prev_end_raw : anchor;  // end of the previous selected match
-            const uint32_t ll = pos - anc, mlc = len - LZ_MINMATCH;       // meaningful on selected lanes
-            // extension bytes: only the FIRST sequence of a window can carry more than 63 literals and only the
-            // LAST match can be longer than the 36-byte cap, so every other lane needs at most one extension
-            // byte (ll - 15 < 255, mlc - 15 < 255); the two special lanes get their counts from scalar code
-            const uint32_t first = (uint32_t)__ffsll((long long)SEL) - 1u;
-            const uint32_t ll_first = p + first - anchor, ml_last = lcur - last - LZ_MINMATCH;
-            const uint32_t llx_first = ll_first >= 15u ? div255(ll_first - 15u) + 1u : 0u;
-            const uint32_t mlx_last = ml_last >= 15u ? div255(ml_last - 15u) + 1u : 0u;
-            const uint32_t llx = lane == first ? llx_first : (ll >= 15u ? 1u : 0u);
-            const uint32_t mlx = lane == last ? mlx_last : (mlc >= 15u ? 1u : 0u);
-            const uint32_t size = (3u + llx + ll + mlx) & selm;
-            uint32_t total;
-            const uint32_t so = wave_incl_scan_dpp(size, lane, &total) - size;
-            // literals: lanes not covered by a selected match that have a selected match above them
-            const uint32_t a_lo = sel_lo & above_lo, a_hi = sel_hi & above_hi;
-            const uint32_t nxt = a_lo ? (uint32_t)__ffs((int)a_lo) - 1u : (a_hi ? 31u + (uint32_t)__ffs((int)a_hi) : lane);
-            const uint32_t base = op + so + 1u + llx - anc;   // on selected lanes: out offset of input byte `anc`... + pos
-            const uint32_t bn = (uint32_t)__shfl((int)base, (int)nxt, 64);
-            const uint32_t oq = op + so;                      // all stores: uniform `out` + 32-bit lane offset
-            if (selm) {
-                // token, then (same lane, program order) the optional one-byte extensions; a lane without an
-                // extension re-writes its own token / high offset byte instead of branching
-                const uint32_t token = ((ll < 15u ? ll : 15u) << 4) | (mlc < 15u ? mlc : 15u);
-                const uint32_t q = oq + 1u + llx + ll;
-                const uint32_t off = pos - cand;
-                out[oq] = (uint8_t)token;
-                out[oq + (llx == 1u ? 1u : 0u)] = (uint8_t)(llx == 1u ? ll - 15u : token);
-                out[q] = (uint8_t)(off & 0xFFu);
-                out[q + 1u] = (uint8_t)(off >> 8);
-                out[q + (mlx == 1u ? 2u : 1u)] = (uint8_t)(mlx == 1u ? mlc - 15u : off >> 8);
-            } else if ((a_lo | a_hi) && pos >= anc) {
-                // not selected, something selected above, not inside the previous selected match
-                out[bn + pos] = (uint8_t)(d & 0xFFu);
+            const bool selb = ((sel_lo & lane_bit_lo) | (sel_hi & lane_bit_hi)) != 0u;
+            const uint32_t rank = (uint32_t)__popc(sel_lo & below_lo) + (uint32_t)__popc(sel_hi & below_hi);
+            if (selb) queue[qn + rank] = make_uint2(pos | (len << 16), pos - cand);
+            qn += (uint32_t)__popcll(SEL);
+            if (qn > 48u) {
+                lz4_flush_queue(in, out, queue, qn, op, anchor, lane);
+                qn = 0u;
             }
-            if ((llx_first | mlx_last) > 1u) {  // rare: 255-runs (long literal run in front / long last match)
-                if (selm && (llx | mlx) > 1u) {
-                    const uint32_t q = oq + 1u + llx + ll;
-                    if (llx > 1u) {
-                        const uint32_t rem = ll - 15u;
-                        for (uint32_t k = 0; k < llx; ++k) out[oq + 1u + k] = (k == llx - 1u) ? (uint8_t)(rem - 255u * (llx - 1u)) : (uint8_t)255u;
-                    }
-                    if (mlx > 1u) {
-                        const uint32_t rem = mlc - 15u;
-                        for (uint32_t k = 0; k < mlx; ++k) out[q + 2u + k] = (k == mlx - 1u) ? (uint8_t)(rem - 255u * (mlx - 1u)) : (uint8_t)255u;
-                    }
-                }
-            }
-            // literals of the first sequence that lie in front of this window (pending from earlier windows)
-            if (anchor < p) {
-                const uint32_t dst0 = op + 1u + llx_first;
-                const uint32_t npre = p - anchor;
-                for (uint32_t k = lane; k < npre; k += 64u) out[dst0 + k] = in[anchor + k];
-            }
-            op += total;
             cur = ncur;
-            anchor = ncur;
             p = np;
             own = nown;
         }
     }
+    if (qn) lz4_flush_queue(in, out, queue, qn, op, anchor, lane);
     {
         const uint32_t ll = n - anchor;
         if (lane == 0) out[op] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
@@ -498,9 +503,10 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
         const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
+        uint2 *queue = reinterpret_cast<uint2 *>((reinterpret_cast<uintptr_t>(tabs + (size_t)nwaves * ((1u << hashlog) + 2u)) + 7u) & ~(uintptr_t)7u) + (size_t)wave * 64u;
         uint32_t cs = ALGO == 1   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                      : ALGO == 5 ? lz4_wave_compress_v4<true>(in, neblock, tb, hashlog, out)
-                                  : lz4_wave_compress_v4<false>(in, neblock, tb, hashlog, out);
+                      : ALGO == 5 ? lz4_wave_compress_v6<true>(in, neblock, tb, hashlog, out, queue)
+                                  : lz4_wave_compress_v6<false>(in, neblock, tb, hashlog, out, queue);
         (void)algo;
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
@@ -534,29 +540,29 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     // relative to the smallest one (512 entries); 160 KiB LDS and 32 waves per CU.
     static const int hl_env = getenv("HHGT_LZ4_HASHLOG") ? atoi(getenv("HHGT_LZ4_HASHLOG")) : 0;
     auto occ = [&](uint32_t hl) {
-        size_t l = data_bytes + (size_t)nwaves * ((2u << hl) + 4u);
+        size_t l = data_bytes + (size_t)nwaves * ((2u << hl) + 4u) + 8u + (size_t)nwaves * 512u;
         size_t by_lds = (160 * 1024) / l, by_waves = 32 / nwaves;
         return by_lds < by_waves ? by_lds : by_waves;
     };
     uint32_t hashlog = 12;
     while (hashlog > 9 && occ(hashlog) < occ(9)) --hashlog;
     if (hl_env >= 8 && hl_env <= 13) hashlog = (uint32_t)hl_env;
-    const size_t lds = data_bytes + (size_t)nwaves * ((2u << hashlog) + 4u);
+    const size_t lds = data_bytes + (size_t)nwaves * ((2u << hashlog) + 4u) + 8u + (size_t)nwaves * 512u;
     if (lds > 160 * 1024 - 64) {
         hhgt_set_error("lz4: block of %d bytes x typesize %d does not fit LDS", blocksize, typesize);
         return HHGT_ERR_ARG;
     }
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in
     if (lds > attr_lds) {
-        const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1>), reinterpret_cast<const void *>(k_lz4_blocks<0, 4>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<0, 5>), reinterpret_cast<const void *>(k_lz4_blocks<8, 5>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<6, 4>), reinterpret_cast<const void *>(k_lz4_blocks<7, 4>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<8, 4>)};
+        const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1>), reinterpret_cast<const void *>(k_lz4_blocks<0, 5>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<8, 5>), reinterpret_cast<const void *>(k_lz4_blocks<0, 6>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<6, 6>), reinterpret_cast<const void *>(k_lz4_blocks<7, 6>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<8, 6>)};
         for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    // HHGT_LZ4_ALGO: 4 = window-parallel encoder (default), 1 = the simple first version (kept for A/B runs)
-    static const uint32_t algo = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 4u;
+    // HHGT_LZ4_ALGO: 6 = window-parallel encoder with batched emission (default), 1 = the simple first version (A/B)
+    static const uint32_t algo = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 6u;
     const uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
     if (grid > 0x7fffffffull) {
@@ -572,10 +578,10 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     if (algo == 1u) LZ_LAUNCH(0, 1);
     else if (fast && nwaves <= 2) LZ_LAUNCH(8, 5);
     else if (fast) LZ_LAUNCH(0, 5);
-    else if (mw == 8) LZ_LAUNCH(8, 4);
-    else if (mw == 7) LZ_LAUNCH(7, 4);
-    else if (mw == 6) LZ_LAUNCH(6, 4);
-    else LZ_LAUNCH(0, 4);
+    else if (mw == 8) LZ_LAUNCH(8, 6);
+    else if (mw == 7) LZ_LAUNCH(7, 6);
+    else if (mw == 6) LZ_LAUNCH(6, 6);
+    else LZ_LAUNCH(0, 6);
 #undef LZ_LAUNCH
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
