@@ -195,14 +195,32 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
     return x;
 }
 
-// FAST = run candidate only (no hash table, no LDS gathers): the low-clevel mode, like LZ4's acceleration.
+// v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (kept opaque so that min() folds stay one instruction)
+__device__ __forceinline__ uint32_t ffbl(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// number of equal leading bytes (0..4) given x = a ^ b
+__device__ __forceinline__ uint32_t eq_bytes3(uint32_t x)
+{
+    const uint32_t t = ffbl(x) >> 3;  // x == 0 -> 0x1FFFFFFF
+    return t < 4u ? t : 4u;
+}
+__device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
 // Layout + emission of the queued sequences, one per lane (lane j = j-th match in stream order).
 // queue[j] = (pos | len << 16, offset).  Updates op (output size so far) and anchor (end of the last match).
 __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__restrict__ out, const uint2 *queue,
                                                 uint32_t qn, uint32_t &op, uint32_t &anchor, uint32_t lane)
 {
     const bool valid = lane < qn;
-    const uint2 e = valid ? queue[lane] : make_uint2(0u, 0u);
+    const uint2 e = queue[lane];  // stale entries beyond qn are masked below
     const uint32_t pos = e.x & 0xFFFFu, len = e.x >> 16, off = e.y;
     const uint32_t endp = pos + len;
     const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)endp, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -222,7 +240,7 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
         out[q + 1u] = (uint8_t)(off >> 8);
         out[q + (mlx == 1u ? 2u : 1u)] = (uint8_t)(mlx == 1u ? mlc - 15u : off >> 8);
     }
-    if (__ballot((llx | mlx) > 1u) != 0ull) {  // rare: 255-runs
+    if (ballot((llx | mlx) > 1u) != 0ull) {  // rare: 255-runs
         if (valid && (llx | mlx) > 1u) {
             const uint32_t q = so + 1u + llx + ll;
             if (llx > 1u) {
@@ -237,7 +255,7 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
     }
     // literals: short runs by their own lane, long runs (> 32 bytes: incompressible stretches) by the whole wave
     const uint32_t lit_dst = so + 1u + llx;
-    unsigned long long big = __ballot(ll > 32u);
+    unsigned long long big = ballot(ll > 32u);
     while (big) {
         const uint32_t j = (uint32_t)__ffsll((long long)big) - 1u;
         big &= big - 1ull;
@@ -247,7 +265,7 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
         for (uint32_t k = lane; k < n_l; k += 64u) out[dst + k] = in[src + k];
     }
     const uint32_t lshort = ll > 32u ? 0u : ll;
-    for (uint32_t k = 0; __ballot(k < lshort) != 0ull; ++k)
+    for (uint32_t k = 0; ballot(k < lshort) != 0ull; ++k)
         if (k < lshort) out[lit_dst + k] = in[prev_end + k];
     op += total;
     anchor = (uint32_t)__builtin_amdgcn_readlane((int)endp, (int)(qn - 1u));
@@ -255,41 +273,41 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
 
 // v6: v4's search and parse (history: DESIGN.md §3.1) with deferred, batched emission (lz4_flush_queue).
 // FAST = run candidate only (no hash table, no LDS gathers): the low-clevel mode, like LZ4's acceleration.
+//
+// PMC of this kernel (tools/pmc_lz4.sh): ~6.7 k VALU + ~5.3 k SALU wave-instructions per 4 KiB stream and the
+// SIMDs' VALU issue slots > 85 % busy — the vector ALU is the bound, LDS (0.6 k) and the scalar unit have
+// room.  So per-lane predicates live as wave masks in SGPR pairs (v_cmp writes them for free), everything
+// wave-uniform (range limits, the position-0 exclusion, end-of-stream clipping) is scalar and branched
+// around, and the enqueue runs under exec = SEL set by two scalar moves instead of a per-lane test.
 template <bool FAST>
 __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint32_t n, uint16_t *tab,
                                                          uint32_t hashlog, uint8_t *__restrict__ out, uint2 *queue)
 {
-    // PMC (profiles/r01_pmc_lz4_v4_sq_*.csv) puts this loop at ~0.75 scalar instructions per cycle per CU:
-    // the CU's single scalar unit is the bound.  Hence: per-lane predicates are kept as 0 / ~0 integers in
-    // VGPRs (mask logic on VCC/SGPR pairs is scalar work), lane-divergent `if`s are merged or replaced by
-    // address selects, and the greedy-parse loop is written so that it compiles to ~8 scalar instructions.
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < (1u << hashlog) / 2u + 1u; i += 64u) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
-    const uint32_t dummy_slot = 1u << hashlog;  // table entry hashed positions never use (insert sink)
-    const uint32_t below_lo = lane >= 32u ? 0xFFFFFFFFu : ((1u << lane) - 1u);
-    const uint32_t below_hi = lane <= 32u ? 0u : ((1u << (lane - 32u)) - 1u);
-    const uint32_t above_lo = lane >= 31u ? 0u : (0xFFFFFFFFu << (lane + 1u));
-    const uint32_t above_hi = lane < 32u ? 0xFFFFFFFFu : (lane == 63u ? 0u : (0xFFFFFFFFu << (lane - 31u)));
-    const uint32_t lane_bit_lo = lane < 32u ? 1u << lane : 0u, lane_bit_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
-    uint32_t op = 0, anchor = 0, cur = 0, qn = 0;
+    const uint32_t to_end = 64u - lane;
+    const uint32_t queue_lds = lds_addr(queue);
+    uint32_t op = 0, anchor = 0, qn = 0;
     if (n > LZ_MFLIMIT) {
         const uint32_t mflimit = n - LZ_MFLIMIT, matchlimit = n - LZ_LASTLITERALS;
         const uint32_t hshift = 32u - hashlog;
+        const uint32_t lim63 = mflimit - 63u;  // p - 1 >= lim63 (unsigned) <=> p == 0 or p + 63 > mflimit
         uint32_t p = 0;
         Own6 own = lds_load6(in, lane);
+        // byte before this lane's position (0x100 = "none": position 0 continues no run)
+        uint32_t pbv = lane ? (uint32_t)in[lane - 1u] : 0x100u;
         while (p <= mflimit) {
             const uint32_t pos = p + lane;
             const uint32_t sh = pos & 3u;
-            uint32_t o[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) o[k] = __builtin_amdgcn_alignbyte(own.w[k + 1], own.w[k], sh);
-            const uint32_t d = o[0];
+            const uint32_t d = __builtin_amdgcn_alignbyte(own.w[1], own.w[0], sh);
             uint32_t hcand = 0u, hsh = 0u;
             Own6 cw;
             if constexpr (!FAST) {
+                // positions past mflimit are inserted too: only the last window has them and nothing reads
+                // the table after it
                 const uint32_t h = (d * 2654435761u) >> hshift;
                 hcand = (uint32_t)tab[h];
-                tab[pos <= mflimit ? h : dummy_slot] = (uint16_t)pos;
+                tab[h] = (uint16_t)pos;
                 cw = lds_load6(in, hcand);
                 hsh = hcand & 3u;
             }
@@ -299,86 +317,96 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             // number of consecutive set bits of E from its own bit (exact up to the window end).  On sparse
             // genotype planes (b) roughly halves what a zero run costs, because an earlier "0000" copy breaks
             // wherever the EARLIER text had a 1 (ratio 3.36 -> 4.35 on the 3 M x 2504 workload).
-            // previous lane's first byte: DPP wave_shr:1 (one VALU op, no LDS round trip on the path to M)
-            const uint32_t dprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x138, 0xf, 0xf, false);
-            const uint32_t pb = lane ? (dprev & 0xFFu) : (p ? (uint32_t)in[p - 1u] : (~d & 0xFFu));
-            const unsigned long long E = __ballot((d & 0xFFu) == pb);
-            const uint32_t E_lo = (uint32_t)E, E_hi = (uint32_t)(E >> 32);
-            // ~(E >> lane) with 32-bit full-rate ops; first set bit = end of this lane's run
-            const uint32_t r_lo = ~(lane < 32u ? __builtin_amdgcn_alignbit(E_hi, E_lo, lane) : E_hi >> (lane - 32u));
-            const uint32_t r_hi = ~(lane < 32u ? E_hi >> lane : 0u);
-            const uint32_t run = r_lo ? (uint32_t)__ffs((int)r_lo) - 1u : 31u + (uint32_t)__ffs((int)r_hi);  // <= 64 - lane
-            uint32_t xh[5] = {1u, 1u, 1u, 1u, 1u};
-            if constexpr (!FAST) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) xh[k] = o[k] ^ __builtin_amdgcn_alignbyte(cw.w[k + 1], cw.w[k], hsh);
+            const unsigned long long E = ballot((d & 0xFFu) == pbv);
+            const unsigned long long r = ~(E >> lane);  // first set bit = end of this lane's run
+            const uint32_t f_lo = ffbl((uint32_t)r), f_hi = ffbl((uint32_t)(r >> 32)) | 32u;
+            const uint32_t f = f_lo < f_hi ? f_lo : f_hi;
+            const uint32_t run = f < 64u ? f : 64u;  // <= 64 - lane
+            // per-lane predicates are wave masks (SGPR pairs written by v_cmp), combined on the scalar unit
+            const unsigned long long Rm = ballot(run >= 4u);
+            unsigned long long Hm = 0ull;
+            if constexpr (!FAST) Hm = ballot(d == __builtin_amdgcn_alignbyte(cw.w[1], cw.w[0], hsh));
+            // the table starts zeroed, so hcand < pos except at position 0; candidates need no range test:
+            // position 0 and lanes past mflimit are taken out of M on the scalar side, in the two windows that have them
+            unsigned long long M = Hm | Rm;
+            if (p - 1u >= lim63) {
+                asm volatile("" ::: "memory");  // keep this a (rarely taken) scalar branch
+                if (p == 0u) M &= ~1ull;
+                if (p + 63u > mflimit) M &= ~0ull >> (63u - (mflimit - p));
             }
-            // usable <=> pos <= mflimit, pos >= cur (and for (a): hcand < pos); >= 4 bytes equal
-            const uint32_t out_of_range = ((mflimit - pos) >> 31) | ((pos - cur) >> 31);
-            const uint32_t bad_h = xh[0] | out_of_range | ((pos - hcand - 1u) >> 31);
-            const uint32_t bad_r = out_of_range | ((run - 4u) >> 31);
-            const unsigned long long M = __ballot((bad_h == 0u) | (bad_r == 0u));
             if (M == 0ull) {
                 p += 64u;
                 own = lds_load6(in, p + lane);
+                pbv = (uint32_t)in[p + lane - 1u];
                 continue;
             }
-            // equal bytes of xh[1..4]: the first non-zero dword decides (all four zero: 4 + 12 + 4 = 20, still matching)
-            const uint32_t t1 = xh[1] ? xh[1] : (xh[2] ? xh[2] : (xh[3] ? xh[3] : xh[4]));
-            const uint32_t skip = xh[1] ? 0u : (xh[2] ? 4u : (xh[3] ? 8u : 12u));
-            const uint32_t lenh = bad_h == 0u ? 4u + skip + eq_bytes(t1) : 0u;
-            uint32_t amh = (bad_h | xh[1] | xh[2] | xh[3] | xh[4]) == 0u ? 0xFFFFFFFFu : 0u;
-            const uint32_t lenr = bad_r == 0u ? run : 0u;
-            const bool use_run = lenr >= lenh;                      // ties go to the run (offset 1)
+            uint32_t lenh = 0u;
+            unsigned long long Zm = 0ull;
+            if constexpr (!FAST) {
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(own.w[2], own.w[1], sh) ^ __builtin_amdgcn_alignbyte(cw.w[2], cw.w[1], hsh);
+                const uint32_t x2 = __builtin_amdgcn_alignbyte(own.w[3], own.w[2], sh) ^ __builtin_amdgcn_alignbyte(cw.w[3], cw.w[2], hsh);
+                const uint32_t x3 = __builtin_amdgcn_alignbyte(own.w[4], own.w[3], sh) ^ __builtin_amdgcn_alignbyte(cw.w[4], cw.w[3], hsh);
+                const uint32_t x4 = __builtin_amdgcn_alignbyte(own.w[5], own.w[4], sh) ^ __builtin_amdgcn_alignbyte(cw.w[5], cw.w[4], hsh);
+                // equal bytes of x1..x4: the first non-zero dword decides (all zero: 16 + 4 = 20, still matching)
+                const uint32_t t1 = x1 ? x1 : (x2 ? x2 : (x3 ? x3 : x4));
+                const uint32_t skip = x1 ? 4u : (x2 ? 8u : (x3 ? 12u : 16u));
+                const uint32_t lraw = skip + eq_bytes3(t1);
+                lenh = __builtin_amdgcn_inverse_ballot_w64(Hm) ? lraw : 0u;
+                Zm = ballot((x1 | x2 | x3 | x4) == 0u);
+            }
+            const uint32_t lenr = __builtin_amdgcn_inverse_ballot_w64(Rm) ? run : 0u;
+            const unsigned long long URm = ballot(lenr >= lenh);  // ties go to the run (offset 1)
+            uint32_t len = lenr > lenh ? lenr : lenh;
+            const uint32_t off = __builtin_amdgcn_inverse_ballot_w64(URm) ? 1u : pos - hcand;
             // "still matching": a run that reaches the window end, or a hash match alive after 20 bytes
-            uint32_t am = use_run ? ((lane + run == 64u && bad_r == 0u) ? 0xFFFFFFFFu : 0u) : amh;
-            uint32_t len = use_run ? lenr : lenh;
-            const uint32_t cand = use_run ? pos - 1u : hcand;
-            const uint32_t csh = cand & 3u;
-            if (!FAST && __ballot(am != 0u && !use_run) != 0ull) {  // second batch: bytes 20..35 of hash matches
-                const Own6 o2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, cand + 20u);
+            const unsigned long long RFm = URm & ballot(lenr == to_end);
+            const unsigned long long MOREm = Hm & Zm & ~URm;
+            unsigned long long LNG = RFm | MOREm;
+            if (!FAST && MOREm != 0ull) {  // second batch: bytes 20..35 of hash matches
+                const Own6 q2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, hcand + 20u);
                 uint32_t y[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    y[k] = __builtin_amdgcn_alignbyte(o2.w[k + 1], o2.w[k], sh) ^ __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], csh);
+                    y[k] = __builtin_amdgcn_alignbyte(q2.w[k + 1], q2.w[k], sh) ^ __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], hsh);
                 const uint32_t t2 = y[0] ? y[0] : (y[1] ? y[1] : (y[2] ? y[2] : y[3]));
                 const uint32_t skip2 = y[0] ? 0u : (y[1] ? 4u : (y[2] ? 8u : 12u));
-                const bool more = !use_run && am != 0u;
-                len += more ? skip2 + eq_bytes(t2) : 0u;
-                const uint32_t amx = (more && (y[0] | y[1] | y[2] | y[3]) == 0u) ? 0xFFFFFFFFu : 0u;
-                am = use_run ? am : amx;
+                len += __builtin_amdgcn_inverse_ballot_w64(MOREm) ? skip2 + eq_bytes3(t2) : 0u;
+                LNG = RFm | (MOREm & ballot((y[0] | y[1] | y[2] | y[3]) == 0u));
             }
-            const uint32_t maxlen = matchlimit - pos;
-            am = len >= maxlen ? 0u : am;        // clipped at the end of the stream: not "long"
-            len = len < maxlen ? len : maxlen;
-            const unsigned long long LNG = __ballot(am != 0u);
-            // ---- greedy parse: the only serial part (scalar unit)
-            unsigned long long SEL = 0ull;
-            uint32_t lcur = cur > p ? cur - p : 0u;
-            uint32_t last = 0u;
-            if (lcur < 64u) {
-                do {
-                    const unsigned long long m = M & (~0ull << lcur);
-                    if (m == 0ull) break;
-                    last = (uint32_t)__ffsll((long long)m) - 1u;
-                    SEL |= 1ull << last;
-                    lcur = last + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)last);
-                } while (lcur < 64u);
+            if (p + 100u > matchlimit) {  // only the last windows of a stream can reach the end-of-block limits
+                asm volatile("" ::: "memory");
+                const uint32_t maxlen = matchlimit - pos;  // lanes past matchlimit are not in M
+                LNG &= ballot(len < maxlen);               // clipped at the end of the stream: not "long"
+                len = len < maxlen ? len : maxlen;
             }
-            if (SEL == 0ull) {
-                p += 64u;
-                own = lds_load6(in, p + lane);
-                continue;
-            }
+            // ---- greedy parse: the only serial part (scalar unit; 8 scalar instructions + one v_readlane per match)
+            unsigned long long SEL, mrest;
+            uint32_t lcur, last;
+            asm volatile("s_mov_b64 %[sel], 0\n\t"
+                         "s_mov_b64 %[m], %[M]\n"
+                         "1:\n\t"
+                         "s_ff1_i32_b64 %[last], %[m]\n\t"
+                         "s_bitset1_b64 %[sel], %[last]\n\t"
+                         "v_readlane_b32 %[lcur], %[len], %[last]\n\t"
+                         "s_add_i32 %[lcur], %[lcur], %[last]\n\t"
+                         "s_cmp_gt_u32 %[lcur], 63\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_lshl_b64 %[m], -1, %[lcur]\n\t"
+                         "s_and_b64 %[m], %[m], %[M]\n\t"
+                         "s_cbranch_scc1 1b\n"
+                         "2:"
+                         : [sel] "=&s"(SEL), [m] "=&s"(mrest), [last] "=&s"(last), [lcur] "=&s"(lcur)
+                         : [M] "s"(M), [len] "v"(len)
+                         : "scc");
             if ((LNG >> last) & 1ull) {
                 // the last match is still matching (36-byte cap, or a run that reaches the window end): finish it
                 const uint32_t ps = p + last;
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)last);
+                const uint32_t c = ps - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)last);
                 uint32_t ml = lcur - last;
                 // most tails are short: first look at the next 64 bytes, one byte per lane
                 const uint32_t kb = ml + lane;
                 const bool eqb = (ps + kb < matchlimit) && in[ps + kb] == in[c + kb];
-                const unsigned long long neb = __ballot(!eqb);
+                const unsigned long long neb = ballot(!eqb);
                 if (neb != 0ull) {
                     ml += (uint32_t)__ffsll((long long)neb) - 1u;
                 } else {
@@ -391,37 +419,43 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                             const uint32_t room = matchlimit - (ps + k);
                             nm = nm < room ? nm : room;
                         }
-                        const unsigned long long stop = __ballot(nm < 4u);
+                        const unsigned long long stop = ballot(nm < 4u);
                         if (stop == 0ull) {
                             ml += 256u;
                             continue;
                         }
-                        const uint32_t f = (uint32_t)__ffsll((long long)stop) - 1u;
-                        ml += 4u * f + (uint32_t)__builtin_amdgcn_readlane((int)nm, (int)f);
+                        const uint32_t f2 = (uint32_t)__ffsll((long long)stop) - 1u;
+                        ml += 4u * f2 + (uint32_t)__builtin_amdgcn_readlane((int)nm, (int)f2);
                         break;
                     }
                 }
                 len = lane == last ? ml : len;
                 lcur = last + ml;
             }
-            // next window's own bytes: request now, consumed after the emission below
-            const uint32_t ncur = p + lcur;
-            const uint32_t np = ncur > p + 64u ? ncur : p + 64u;
+            // next window's own bytes: request now, consumed after the enqueue below
+            const uint32_t np = p + (lcur > 64u ? lcur : 64u);
             const Own6 nown = lds_load6(in, np + lane);
-            // ---- enqueue the selected matches; layout + emission happen once per ~16 windows (flush), one
+            const uint32_t npbv = (uint32_t)in[np + lane - 1u];
+            // ---- enqueue the selected matches; layout + emission happen once per ~12 windows (flush), one
             //      sequence per lane, instead of once per window with 4 of 64 lanes busy
-            const uint32_t sel_lo = (uint32_t)SEL, sel_hi = (uint32_t)(SEL >> 32);
-            const bool selb = ((sel_lo & lane_bit_lo) | (sel_hi & lane_bit_hi)) != 0u;
-            const uint32_t rank = (uint32_t)__popc(sel_lo & below_lo) + (uint32_t)__popc(sel_hi & below_hi);
-            if (selb) queue[qn + rank] = make_uint2(pos | (len << 16), pos - cand);
+            {
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(SEL >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)SEL, qn));
+                const uint32_t addr = queue_lds + slot * 8u;
+                const unsigned long long ent = (unsigned long long)(pos | (len << 16)) | ((unsigned long long)off << 32);
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved)
+                             : "s"(SEL), "v"(addr), "v"(ent)
+                             : "memory");
+            }
             qn += (uint32_t)__popcll(SEL);
             if (qn > 48u) {
                 lz4_flush_queue(in, out, queue, qn, op, anchor, lane);
                 qn = 0u;
             }
-            cur = ncur;
             p = np;
             own = nown;
+            pbv = npbv;
         }
     }
     if (qn) lz4_flush_queue(in, out, queue, qn, op, anchor, lane);
@@ -503,7 +537,9 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
         const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
-        uint2 *queue = reinterpret_cast<uint2 *>((reinterpret_cast<uintptr_t>(tabs + (size_t)nwaves * ((1u << hashlog) + 2u)) + 7u) & ~(uintptr_t)7u) + (size_t)wave * 64u;
+        // sequence queue: 64 entries per wave, 8-aligned after the tables (offset arithmetic keeps the LDS address space)
+        const uint32_t qoff = (nwaves * sstride + 16u + nwaves * ((2u << hashlog) + 4u) + 7u) & ~7u;
+        uint2 *queue = reinterpret_cast<uint2 *>(smem + qoff) + wave * 64u;
         uint32_t cs = ALGO == 1   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
                       : ALGO == 5 ? lz4_wave_compress_v6<true>(in, neblock, tb, hashlog, out, queue)
                                   : lz4_wave_compress_v6<false>(in, neblock, tb, hashlog, out, queue);
