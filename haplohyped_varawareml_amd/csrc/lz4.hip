@@ -208,6 +208,13 @@ __device__ __forceinline__ uint32_t eq_bytes3(uint32_t x)
     const uint32_t t = ffbl(x) >> 3;  // x == 0 -> 0x1FFFFFFF
     return t < 4u ? t : 4u;
 }
+// NOTE on unaligned LDS reads: gfx950 accepts ds_read_b32/b64/b128 at any byte address, which would remove every
+// v_alignbyte below — but tools/micro/lds_unaligned.hip measures ~57 cycles per unaligned wave-instruction
+// (lanes serialised, any width) against 3-5 aligned; the encoder built that way ran 3.3x slower.  Aligned
+// dwords + v_alignbyte it is.
+struct __attribute__((packed)) PackedU32 {
+    uint32_t v;
+};
 __device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 __device__ __forceinline__ uint32_t lds_addr(const void *p)
 {
@@ -264,9 +271,25 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
         const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)lit_dst, (int)j);
         for (uint32_t k = lane; k < n_l; k += 64u) out[dst + k] = in[src + k];
     }
+    // short runs: 4 bytes per step from two aligned LDS dwords; whole dwords go out as one (unaligned) global
+    // store, the last 1-3 bytes one by one (the bytes after them belong to other lanes)
     const uint32_t lshort = ll > 32u ? 0u : ll;
-    for (uint32_t k = 0; ballot(k < lshort) != 0ull; ++k)
-        if (k < lshort) out[lit_dst + k] = in[prev_end + k];
+    const uint32_t lsh = prev_end & 3u;
+    for (uint32_t k = 0; ballot(k < lshort) != 0ull; k += 4u) {
+        if (k < lshort) {
+            const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(in) + ((prev_end + k) >> 2);
+            const uint32_t v = __builtin_amdgcn_alignbyte(wsrc[1], wsrc[0], lsh);
+            const uint32_t rem = lshort - k;
+            uint8_t *dstp = out + lit_dst + k;
+            if (rem >= 4u) {
+                reinterpret_cast<PackedU32 *>(dstp)->v = v;
+            } else {
+                dstp[0] = (uint8_t)v;
+                if (rem > 1u) dstp[1] = (uint8_t)(v >> 8);
+                if (rem > 2u) dstp[2] = (uint8_t)(v >> 16);
+            }
+        }
+    }
     op += total;
     anchor = (uint32_t)__builtin_amdgcn_readlane((int)endp, (int)(qn - 1u));
 }
@@ -318,10 +341,10 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             // genotype planes (b) roughly halves what a zero run costs, because an earlier "0000" copy breaks
             // wherever the EARLIER text had a 1 (ratio 3.36 -> 4.35 on the 3 M x 2504 workload).
             const unsigned long long E = ballot((d & 0xFFu) == pbv);
-            const unsigned long long r = ~(E >> lane);  // first set bit = end of this lane's run
+            const unsigned long long r = ~E >> lane;  // first set bit = end of this lane's run (none: the window end)
             const uint32_t f_lo = ffbl((uint32_t)r), f_hi = ffbl((uint32_t)(r >> 32)) | 32u;
             const uint32_t f = f_lo < f_hi ? f_lo : f_hi;
-            const uint32_t run = f < 64u ? f : 64u;  // <= 64 - lane
+            const uint32_t run = f < to_end ? f : to_end;
             // per-lane predicates are wave masks (SGPR pairs written by v_cmp), combined on the scalar unit
             const unsigned long long Rm = ballot(run >= 4u);
             unsigned long long Hm = 0ull;
@@ -405,8 +428,8 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 uint32_t ml = lcur - last;
                 // most tails are short: first look at the next 64 bytes, one byte per lane
                 const uint32_t kb = ml + lane;
-                const bool eqb = (ps + kb < matchlimit) && in[ps + kb] == in[c + kb];
-                const unsigned long long neb = ballot(!eqb);
+                const uint32_t room = matchlimit - (ps + ml);  // > 0: a match that reached matchlimit is not in LNG
+                const unsigned long long neb = ballot(in[ps + kb] != in[c + kb]) | (room < 64u ? ~0ull << room : 0ull);
                 if (neb != 0ull) {
                     ml += (uint32_t)__ffsll((long long)neb) - 1u;
                 } else {
@@ -439,8 +462,8 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             // ---- enqueue the selected matches; layout + emission happen once per ~12 windows (flush), one
             //      sequence per lane, instead of once per window with 4 of 64 lanes busy
             {
-                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(SEL >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)SEL, qn));
-                const uint32_t addr = queue_lds + slot * 8u;
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(SEL >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)SEL, 0u));
+                const uint32_t addr = (queue_lds + qn * 8u) + slot * 8u;  // scalar base + lane slot
                 const unsigned long long ent = (unsigned long long)(pos | (len << 16)) | ((unsigned long long)off << 32);
                 unsigned long long saved;
                 asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
@@ -583,7 +606,10 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     uint32_t hashlog = 12;
     while (hashlog > 9 && occ(hashlog) < occ(9)) --hashlog;
     if (hl_env >= 8 && hl_env <= 13) hashlog = (uint32_t)hl_env;
-    const size_t lds = data_bytes + (size_t)nwaves * ((2u << hashlog) + 4u) + 8u + (size_t)nwaves * 512u;
+    // HHGT_LZ4_LDSPAD: extra dynamic LDS per workgroup — an experiment knob that caps how many LZ4 workgroups
+    // share a CU, leaving LDS for the HBM-bound kernels of the other stream
+    static const size_t lds_pad = getenv("HHGT_LZ4_LDSPAD") ? (size_t)atoi(getenv("HHGT_LZ4_LDSPAD")) : 0;
+    const size_t lds = data_bytes + (size_t)nwaves * ((2u << hashlog) + 4u) + 8u + (size_t)nwaves * 512u + lds_pad;
     if (lds > 160 * 1024 - 64) {
         hhgt_set_error("lz4: block of %d bytes x typesize %d does not fit LDS", blocksize, typesize);
         return HHGT_ERR_ARG;
