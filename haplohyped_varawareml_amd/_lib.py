@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhhgt.so")
+# HHGT_LIB: load another build of the same library (development: tools/lz4_stats.py uses a -DHHGT_LZ4_STATS build)
+LIB_PATH = os.environ.get("HHGT_LIB") or os.path.join(HERE, "libhhgt.so")
 
 OK = 0
 BLOSC1 = 1

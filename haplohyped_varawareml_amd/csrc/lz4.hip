@@ -195,6 +195,26 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x, uint32_t lane
     return x;
 }
 
+#ifdef HHGT_LZ4_STATS
+// development build only (tools/lz4_stats.py): event counts of the window loop
+__device__ unsigned long long g_lz4_stat[8];
+#define LZ_STAT(i, v)                                                                \
+    do {                                                                             \
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_lz4_stat[i], (unsigned long long)(v)); \
+    } while (0)
+extern "C" int hhgt_debug_lz4_stats(unsigned long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lz4_stat), sizeof(g_lz4_stat)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lz4_stat), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define LZ_STAT(i, v) ((void)0)
+#endif
+
 // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (kept opaque so that min() folds stay one instruction)
 __device__ __forceinline__ uint32_t ffbl(uint32_t x)
 {
@@ -319,7 +339,9 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
         Own6 own = lds_load6(in, lane);
         // byte before this lane's position (0x100 = "none": position 0 continues no run)
         uint32_t pbv = lane ? (uint32_t)in[lane - 1u] : 0x100u;
+        LZ_STAT(0, 1);
         while (p <= mflimit) {
+            LZ_STAT(1, 1);
             const uint32_t pos = p + lane;
             const uint32_t sh = pos & 3u;
             const uint32_t d = __builtin_amdgcn_alignbyte(own.w[1], own.w[0], sh);
@@ -358,6 +380,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 if (p + 63u > mflimit) M &= ~0ull >> (63u - (mflimit - p));
             }
             if (M == 0ull) {
+                LZ_STAT(2, 1);
                 p += 64u;
                 own = lds_load6(in, p + lane);
                 pbv = (uint32_t)in[p + lane - 1u];
@@ -378,24 +401,34 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 Zm = ballot((x1 | x2 | x3 | x4) == 0u);
             }
             const uint32_t lenr = __builtin_amdgcn_inverse_ballot_w64(Rm) ? run : 0u;
+            if constexpr (!FAST) {
+                // A hash match that starts 1 or 2 bytes before a run and ends inside it is a bad buy: "match, then
+                // the rest of the run" is two sequences (>= 6 bytes) where "1-2 literals, then the whole run" is one
+                // (<= 5).  On sparse genotype planes that is every '1' followed by zeros (the typical window):
+                // such candidates are dropped, and with them the reason to measure hash matches past 20 bytes
+                // (a second compare batch for bytes 20..35 ran in 80 % of the windows, tools/lz4_stats.py).
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lenr, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                const uint32_t r2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r1, 0x130, 0xf, 0xf, false);
+                const unsigned long long DOMm = (ballot(r1 + 1u > lenh) & (Rm >> 1)) | (ballot(r2 + 2u > lenh) & (Rm >> 2));  // Rm >> k: lane + k starts a run
+                const unsigned long long drop = Hm & DOMm & ~Rm;  // lanes with a run of their own stay candidates
+                Hm &= ~DOMm;
+                M &= ~drop;
+                lenh = __builtin_amdgcn_inverse_ballot_w64(Hm) ? lenh : 0u;
+                if (M == 0ull) {
+                    p += 64u;
+                    own = lds_load6(in, p + lane);
+                    pbv = (uint32_t)in[p + lane - 1u];
+                    continue;
+                }
+            }
             const unsigned long long URm = ballot(lenr >= lenh);  // ties go to the run (offset 1)
             uint32_t len = lenr > lenh ? lenr : lenh;
             const uint32_t off = __builtin_amdgcn_inverse_ballot_w64(URm) ? 1u : pos - hcand;
-            // "still matching": a run that reaches the window end, or a hash match alive after 20 bytes
+            // "still matching": a run that reaches the window end, or a hash match alive after 20 bytes —
+            // finished cooperatively if it is the window's last match
             const unsigned long long RFm = URm & ballot(lenr == to_end);
             const unsigned long long MOREm = Hm & Zm & ~URm;
             unsigned long long LNG = RFm | MOREm;
-            if (!FAST && MOREm != 0ull) {  // second batch: bytes 20..35 of hash matches
-                const Own6 q2 = lds_load6(in, pos + 20u), c2 = lds_load6(in, hcand + 20u);
-                uint32_t y[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    y[k] = __builtin_amdgcn_alignbyte(q2.w[k + 1], q2.w[k], sh) ^ __builtin_amdgcn_alignbyte(c2.w[k + 1], c2.w[k], hsh);
-                const uint32_t t2 = y[0] ? y[0] : (y[1] ? y[1] : (y[2] ? y[2] : y[3]));
-                const uint32_t skip2 = y[0] ? 0u : (y[1] ? 4u : (y[2] ? 8u : 12u));
-                len += __builtin_amdgcn_inverse_ballot_w64(MOREm) ? skip2 + eq_bytes3(t2) : 0u;
-                LNG = RFm | (MOREm & ballot((y[0] | y[1] | y[2] | y[3]) == 0u));
-            }
             if (p + 100u > matchlimit) {  // only the last windows of a stream can reach the end-of-block limits
                 asm volatile("" ::: "memory");
                 const uint32_t maxlen = matchlimit - pos;  // lanes past matchlimit are not in M
@@ -423,6 +456,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                          : "scc");
             if ((LNG >> last) & 1ull) {
                 // the last match is still matching (36-byte cap, or a run that reaches the window end): finish it
+                LZ_STAT(4, 1);
                 const uint32_t ps = p + last;
                 const uint32_t c = ps - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)last);
                 uint32_t ml = lcur - last;
@@ -433,6 +467,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 if (neb != 0ull) {
                     ml += (uint32_t)__ffsll((long long)neb) - 1u;
                 } else {
+                    LZ_STAT(5, 1);
                     ml += 64u;
                     for (;;) {  // a long run: 256 bytes per step
                         const uint32_t k = ml + 4u * lane;
@@ -472,7 +507,9 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                              : "memory");
             }
             qn += (uint32_t)__popcll(SEL);
+            LZ_STAT(7, __popcll(SEL));
             if (qn > 48u) {
+                LZ_STAT(6, 1);
                 lz4_flush_queue(in, out, queue, qn, op, anchor, lane);
                 qn = 0u;
             }
