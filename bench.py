@@ -218,10 +218,11 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected
     # in separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch size
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))   # newest build last (r01, r01b, r02 ...)
+    if pmcs:
         try:
-            per_variant = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_variant")
+            per_variant = json.load(open(pmcs[-1])).get(dom, {}).get("hbm_bytes_per_variant")
             if per_variant and S == 2504:
                 traffic = per_variant * my_variants / max(len(shards), 1)
         except Exception:
@@ -231,6 +232,9 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "bytes_per_launch": dom_bytes_per_launch, "ms_per_launch": dom_ms_per_launch}
+    if dom == "lz4":
+        # the contract's roofline is HBM or MFMA; this kernel is bound by neither
+        roof["limiter"] = "instruction issue: VALU and scalar unit ~90 % busy per PMC (profiles/*_pmc_lz4_sq.csv), HBM idle"
 
     out = {
         "metric": "variants/sec encode+compress, 3M-variant x 2.5k-sample VCF",

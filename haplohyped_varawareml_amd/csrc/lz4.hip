@@ -407,8 +407,8 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 // (<= 5).  On sparse genotype planes that is every '1' followed by zeros (the typical window):
                 // such candidates are dropped, and with them the reason to measure hash matches past 20 bytes
                 // (a second compare batch for bytes 20..35 ran in 80 % of the windows, tools/lz4_stats.py).
-                const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lenr, 0x130, 0xf, 0xf, false);  // wave_shl:1
-                const uint32_t r2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r1, 0x130, 0xf, 0xf, false);
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lenr, 0x130, 0xf, 0xf, true);  // wave_shl:1, 0 shifted in
+                const uint32_t r2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r1, 0x130, 0xf, 0xf, true);
                 const unsigned long long DOMm = (ballot(r1 + 1u > lenh) & (Rm >> 1)) | (ballot(r2 + 2u > lenh) & (Rm >> 2));  // Rm >> k: lane + k starts a run
                 const unsigned long long drop = Hm & DOMm & ~Rm;  // lanes with a run of their own stay candidates
                 Hm &= ~DOMm;

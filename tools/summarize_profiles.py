@@ -1,0 +1,69 @@
+"""gpurun_out/prof_<tag>/ -> profiles/<prefix>_*: copies the rocprofv3 summaries worth keeping and writes the
+per-variant HBM byte counts (FETCH_SIZE x 2 on gfx950, WRITE_SIZE; MI355X_MICROARCH.md §HBM) as json.
+usage: python tools/summarize_profiles.py <tag> <prefix>      e.g.  r01b r01b"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag, prefix = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", "prof_" + tag)
+os.makedirs("profiles", exist_ok=True)
+
+
+def find(suffix, start):
+    for root, _, files in os.walk(src):
+        for f in files:
+            if f.startswith(start) and f.endswith(suffix):
+                return os.path.join(root, f)
+    raise FileNotFoundError((start, suffix))
+
+
+shutil.copy(find("kernel_stats.csv", tag), f"profiles/{prefix}_bench_kernel_stats.csv")
+shutil.copy(os.path.join(src, "bench_line.json"), f"profiles/{prefix}_bench_line.json")
+shutil.copy(os.path.join(src, "bench_line_under_rocprof.json"), f"profiles/{prefix}_bench_line_under_rocprof.json")
+VARIANTS = 300000
+PASSES = 2   # bench.py runs one serial profiling pass + the timed step
+
+
+def per_kernel(path, counter):
+    acc, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        acc[k] += float(r["Counter_Value"])
+        n[k] += 1
+    return acc, n
+
+
+f, nf = per_kernel(find("counter_collection.csv", "f_"), "FETCH_SIZE")
+w, _ = per_kernel(find("counter_collection.csv", "w_"), "WRITE_SIZE")
+out = {
+    "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh) on `bench.py --variants "
+               f"{VARIANTS} --steps 1 --warmup 0 --no-overlap` = {PASSES} passes over {VARIANTS} variants x 2504 samples",
+    "_correction": "FETCH_SIZE is in KB and counts 64 B per 128-B request for wide coalesced reads on gfx950 "
+                   "(MI355X_MICROARCH.md §HBM): fetch bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 is exact",
+    "variants_per_pass": VARIANTS,
+}
+for name, kern in (("lz4", "k_lz4_blocks"), ("encode", "k_encode_tiles"), ("index", "k_index_newlines"),
+                   ("frame", "k_frame_write"), ("fixed", "k_parse_fixed")):
+    if kern not in f:
+        continue
+    fb = f[kern] * 1024 * 2 / (VARIANTS * PASSES)
+    wb = w[kern] * 1024 / (VARIANTS * PASSES)
+    out[name] = {"kernel": kern, "fetch_bytes_per_variant": fb, "write_bytes_per_variant": wb,
+                 "hbm_bytes_per_variant": fb + wb, "launches": nf[kern]}
+json.dump(out, open(f"profiles/{prefix}_pmc_summary.json", "w"), indent=1)
+shutil.copy(find("counter_collection.csv", "sq_"), f"profiles/{prefix}_pmc_lz4_sq.csv")
+acc, n = collections.defaultdict(float), collections.Counter()
+grid = 0
+for r in csv.DictReader(open(f"profiles/{prefix}_pmc_lz4_sq.csv")):
+    acc[r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_WAVES":
+        grid += int(r["Grid_Size"])
+streams = grid / 64
+print("lz4 per 4 KiB stream:", {k: round(v / streams, 1) for k, v in sorted(acc.items())})
+print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
