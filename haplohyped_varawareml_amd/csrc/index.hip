@@ -17,6 +17,8 @@
 //   per-record table (start, stop, ref, alt) is written at v_base + k.
 #include "common.h"
 
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+
 __device__ __forceinline__ uint32_t nl_mask4(uint32_t x)
 {
     // exact per-byte "== '\n'" -> bit k set for byte k
@@ -109,14 +111,40 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ l_flags, uint32_t *__restrict__ l_keep,
                                                      uint32_t *__restrict__ l_cnew, DevCounters *cnt)
 {
+    // The walk below is byte-serial per line; straight from global memory that is ~80 dependent loads per lane with
+    // every wave of the grid resident at once, i.e. the kernel lasts one full latency chain (89 us for 136 k lines).
+    // So the first 64 bytes of every line (CHROM .. FORMAT of a typical record) are fetched up front by four
+    // independent 16-byte loads per lane and parked in LDS (row stride 17 dwords: conflict-free byte reads);
+    // rd() serves the walk from there and falls back to global memory past byte 64.
+    __shared__ uint32_t stage[256][17];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t flags = 0;
+    uint32_t s = 0, e = 0;
+    bool staged = false;
     if (i < n_lines) {
-        uint32_t s = i ? nl[i - 1] + 1u : 0u;
-        uint32_t e = nl[i];
-        if (e > s && text[e - 1] == '\r') --e;  // bgzf_getline strips a trailing CR
+        s = i ? nl[i - 1] + 1u : 0u;
+        e = nl[i];
+        staged = (uint64_t)s + 64ull <= n;
+        if (staged) {
+            u32x4_unaligned c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = *reinterpret_cast<const u32x4_unaligned *>(text + s + 16 * k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                stage[threadIdx.x][4 * k + 0] = c[k].x;
+                stage[threadIdx.x][4 * k + 1] = c[k].y;
+                stage[threadIdx.x][4 * k + 2] = c[k].z;
+                stage[threadIdx.x][4 * k + 3] = c[k].w;
+            }
+        }
+    }
+    __syncthreads();
+    const uint8_t *mine = reinterpret_cast<const uint8_t *>(stage[threadIdx.x]);
+    auto rd = [&](uint32_t x) -> uint32_t { return (staged && x - s < 64u) ? (uint32_t)mine[x - s] : (uint32_t)text[x]; };
+    if (i < n_lines) {
+        if (e > s && rd(e - 1u) == '\r') --e;  // bgzf_getline strips a trailing CR
         uint32_t soff = e, pos0 = 0, refalt = 0, gtidx = 0;
-        if (e > s && text[s] != '#') {
+        if (e > s && rd(s) != '#') {
             flags = LF_RECORD;
             // walk the first 9 tab-separated fields
             uint32_t fs[10];
@@ -124,7 +152,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
             uint32_t p = s;
             fs[0] = s;
             while (p < e && nf < 9) {
-                if (text[p] == '\t') fs[++nf] = p + 1;
+                if (rd(p) == '\t') fs[++nf] = p + 1;
                 ++p;
             }
             // nf = number of tabs found (<= 9); field k spans [fs[k], fs[k+1]-1) for k < nf
@@ -138,7 +166,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                 unsigned long long pos = 0;
                 if (fe[1] == fs[1]) bad = true;
                 for (uint32_t q = fs[1]; q < fe[1]; ++q) {
-                    uint32_t c = text[q];
+                    uint32_t c = rd(q);
                     if (c < '0' || c > '9') {
                         bad = true;
                         break;
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                     uint32_t cl = fe[0] - fs[0];
                     in_region = cl == (uint32_t)rf->contig_len;
                     for (uint32_t q = 0; in_region && q < cl; ++q)
-                        in_region = text[fs[0] + q] == (uint8_t)rf->contig[q];
+                        in_region = rd(fs[0] + q) == (uint32_t)(uint8_t)rf->contig[q];
                     if (in_region && rf->has_range)
                         in_region = (long long)pos >= rf->beg && (long long)pos <= rf->end;
                 }
@@ -160,21 +188,21 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                     else {
                         // isSNP (cpp/vcfpp.h:990-1000): |REF| <= 1, n_allele <= 2, ALT in {A,C,G,T}
                         uint32_t reflen = fe[3] - fs[3], altlen = fe[4] - fs[4];
-                        uint32_t a = altlen == 1 ? text[fs[4]] : 0;
+                        uint32_t a = altlen == 1 ? rd(fs[4]) : 0;
                         bool snp = reflen == 1 && altlen == 1 && (a == 'A' || a == 'C' || a == 'G' || a == 'T');
                         if (!snp)
                             flags |= LF_DROP_FILTER;
                         else {
                             pos0 = (uint32_t)(pos - 1ull);  // vcfpp.h:1118-1121
-                            refalt = (uint32_t)text[fs[3]] | (a << 8);
+                            refalt = rd(fs[3]) | (a << 8);
                             if (S > 0) {
                                 // GT key index inside FORMAT (bcf_get_genotypes looks the key up)
                                 uint32_t q = fs[8], k = 0;
                                 bool found = false;
                                 while (q <= fe[8]) {
                                     uint32_t q2 = q;
-                                    while (q2 < fe[8] && text[q2] != ':') ++q2;
-                                    if (q2 - q == 2 && text[q] == 'G' && text[q + 1] == 'T') {
+                                    while (q2 < fe[8] && rd(q2) != ':') ++q2;
+                                    if (q2 - q == 2 && rd(q) == 'G' && rd(q + 1u) == 'T') {
                                         found = true;
                                         break;
                                     }
@@ -201,12 +229,16 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
             if (i > 0) {
                 uint32_t ps = i > 1 ? nl[i - 2] + 1u : 0u;
                 uint32_t pe = nl[i - 1];
-                if (pe > ps && text[ps] != '#') {
+                // the previous line sits in the neighbouring thread's LDS row (same staging rule) unless this is thread 0
+                const bool pstaged = threadIdx.x > 0u && (uint64_t)ps + 64ull <= n;
+                const uint8_t *prev = reinterpret_cast<const uint8_t *>(stage[threadIdx.x > 0u ? threadIdx.x - 1u : 0u]);
+                auto rdp = [&](uint32_t x) -> uint32_t { return (pstaged && x - ps < 64u) ? (uint32_t)prev[x - ps] : (uint32_t)text[x]; };
+                if (pe > ps && rdp(ps) != '#') {
                     uint32_t q = 0;
                     cnew = false;
                     for (;;) {
-                        uint32_t a = fs[0] + q < e ? text[fs[0] + q] : '\t';
-                        uint32_t b = ps + q < pe ? text[ps + q] : '\t';
+                        uint32_t a = fs[0] + q < e ? rd(fs[0] + q) : '\t';
+                        uint32_t b = ps + q < pe ? rdp(ps + q) : '\t';
                         if (a != b) {
                             cnew = true;
                             break;
