@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one GPU in rehearsals")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
+    ap.add_argument("--cpu-extended", action="store_true", help="also time the all-cores and the reference-shaped CPU baselines")
     return ap.parse_args()
 
 
@@ -114,7 +115,7 @@ def one_step(ctx, shards, S, blocksize, streams=None):
             sh.cmp_done = s_cmp.record_event()
 
 
-def cpu_baseline(ctx, shards, S, target_s):
+def cpu_baseline(ctx, shards, S, target_s, extended=False):
     """oracle (CPU restatement of the reference path, matrix-shaped, 1 thread) on a bounded sample of
     the same workload: the first n lines of the largest shard."""
     from oracle import oracle
@@ -143,9 +144,52 @@ def cpu_baseline(ctx, shards, S, target_s):
     per_line = (te + tc) / max(V0, 1)
     n = int(min(sh.V, max(4000, target_s / max(per_line, 1e-9))))
     V, te, tc, cb, raw = run(n)
-    return {
+    out = {
         "value": V / (te + tc), "unit": "variants/s", "cores": 1, "kind": "port",
         "sample": f"first {V} variants of {sh.contig} ({S} samples): oracle encode {te:.2f}s + shuffle/LZ4/Blosc2 {tc:.2f}s, ratio {raw / max(cb, 1):.2f}",
+    }
+    if extended:
+        out.update(cpu_baseline_extended(oracle, sh, S, bytes_per_line, n))
+    return out
+
+
+def cpu_baseline_extended(oracle, sh, S, bytes_per_line, n_lines):
+    """SURVEY.md §8d's other two baseline shapes (--cpu-extended; not part of the default run):
+    matrix-shaped on all host cores (the oracle is plain C behind ctypes: threads run it in parallel) and
+    reference-shaped — one call per sample that rescans the whole text, as /root/reference/cpp/parse_vcf.cpp:30-71
+    is driven by vcf_to_h5.py:96-101 — timed for a few samples and scaled to S calls."""
+    from concurrent.futures import ThreadPoolExecutor
+    nb = min(sh.nbytes, int(n_lines * bytes_per_line) + 65536)
+    host = sh.text[:nb].cpu().numpy()
+    host = host[:int(np.flatnonzero(host == 10)[-1]) + 1]
+    T = min(os.cpu_count() or 1, 64)
+    nl = np.flatnonzero(host == 10)
+    cuts = [0] + [int(nl[min(len(nl) - 1, (len(nl) * (i + 1)) // T - 1)]) + 1 for i in range(T)]
+    pieces = [host[cuts[i]:cuts[i + 1]] for i in range(T) if cuts[i + 1] > cuts[i]]
+
+    def work(piece):
+        o = oracle.vcf_encode(piece, S, region=sh.contig)
+        G = o["G"]
+        for s0 in range(0, S, 64):
+            raw = np.ascontiguousarray(G[s0:s0 + 64]).reshape(-1).view(np.uint8)
+            oracle.blosc_compress(raw, 2, min(G.shape[1] * 2, 65536))
+        return G.shape[1]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        Vall = sum(ex.map(work, pieces))
+    t_all = time.perf_counter() - t0
+    # reference-shaped: 3 single-sample calls over a 20 k-line slice
+    k = min(len(nl), 20000)
+    sl = host[:int(nl[k - 1]) + 1]
+    t0 = time.perf_counter()
+    for si in (0, S // 2, S - 1):
+        oracle.vcf_load_sample(sl, S, si, region=sh.contig)
+    t_call = (time.perf_counter() - t0) / 3
+    return {
+        "all_cores": {"value": Vall / t_all, "unit": "variants/s", "cores": T, "sample": f"{Vall} variants in {len(pieces)} line-aligned pieces"},
+        "reference_shaped": {"value": k / (t_call * S), "unit": "variants/s", "cores": 1,
+                             "sample": f"one rescan per sample ({t_call * 1e3:.1f} ms per call over {k} lines) x {S} samples, parse only"},
     }
 
 
@@ -254,7 +298,7 @@ def main():
         "stages_ms_per_step_timed_region": {k: v["ms"] / args.steps for k, v in stages.items()},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ctx, shards, S, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(ctx, shards, S, args.cpu_seconds, args.cpu_extended)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
