@@ -10,12 +10,13 @@
 // Workgroup = one block; wave j = stream j (byte plane j of the shuffled block when split).
 //   phase A  all waves: coalesced 16 B/lane loads of the block, byte-plane de-interleave in registers
 //            (v_perm_b32 for typesize 2), planes stored to LDS  -> shuffle costs no extra HBM traffic
-//   phase B  wave j: greedy LZ4 over its plane in LDS, 64 positions (one per lane) per step
-//            (lz4_wave_compress_v4): every lane verifies and measures its own candidates — the hash table's
-//            most recent occurrence and the offset-1 run — from registers; the greedy left-to-right choice of
-//            non-overlapping matches is the only serial part and runs on the scalar unit; all sequences of
-//            the window are laid out with a DPP prefix sum and written by their own lanes.
-//            lz4_wave_compress (v1: one match per round trip) is kept as a second instantiation for A/B runs.
+//   phase B  wave j: greedy LZ4 over its plane in LDS, 64 positions (one per lane) per window
+//            (lz4_wave_compress_v6): every lane verifies and measures its own candidates — the hash table's
+//            most recent occurrence and the offset-1 run; the greedy left-to-right choice of non-overlapping
+//            matches is the only serial part and runs on the scalar unit; the chosen sequences are queued in LDS
+//            and laid out (DPP prefix sum) and written one per lane, 48-64 at a time.
+//            lz4_wave_compress (v1: one match per round trip) is kept as a second instantiation for A/B runs
+//            (HHGT_LZ4_ALGO=1).
 // Algorithmic bytes = blocksize read + compressed bytes written per block; measured: the kernel is bound by
 // instruction issue, not by HBM.
 #include "common.h"
@@ -129,15 +130,9 @@ __device__ __forceinline__ uint32_t lz4_wave_compress(const uint8_t *in, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// helpers shared by the window-parallel encoder (v2/v3 history: DESIGN.md §3.1).  v3 cut the dependent
-// LDS round trips down (the kernel is latency/issue bound, not HBM bound):
-//   * each lane fetches 24 bytes of its own position and 24 bytes of its candidate in ONE batch of
-//     ds_read2_b32 and measures its match up to 20 bytes from registers; a second batch (to 36 bytes)
-//     runs only when some lane is still matching,
-//   * the window's output layout (sequence sizes, running anchor, running output offset) is computed on
-//     the SCALAR unit inside the greedy selection loop and dropped into the selected lanes with
-//     v_writelane -> no wave prefix scan, no cross-lane shuffles except one for the literal scatter,
-//   * the next window's own bytes are requested before the current window is emitted.
+// helpers of the window-parallel encoder (its history, v2 .. v6: DESIGN.md §3.1).
+// A lane fetches the 24 bytes at its own position and the 24 bytes at its candidate as aligned dwords
+// (ds_read2_b32 x 3 per side) and measures its match up to 20 bytes from registers.
 struct Own6 {
     uint32_t w[6];
 };
@@ -151,23 +146,10 @@ __device__ __forceinline__ Own6 lds_load6(const uint8_t *in, uint32_t pos)
     return o;
 }
 
-// number of equal leading bytes (0..4) given x = a ^ b
-__device__ __forceinline__ uint32_t eq_bytes(uint32_t x)
-{
-    const uint32_t t = (uint32_t)(__ffs((int)x) - 1) >> 3;  // x == 0 -> 0xFFFFFFFF >> 3
-    return t < 4u ? t : 4u;
-}
-
 __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x * 0x8081u) >> 23; }  // exact for x < 65536
 
 // ---------------------------------------------------------------------------------------------
-// v4: PMC counters of v3 showed ~325 SALU + ~190 VALU instructions per 64-byte window — the shared
-// scalar unit (1 instruction / cycle / CU), not HBM or LDS, bounded the kernel.  v4 keeps only the
-// irreducible part of the greedy parse on the scalar unit (mask, s_ff1, v_readlane, bit-set: ~9
-// instructions per match) and derives the whole output layout lane-parallel from the SEL mask:
-// previous/next selected lane by per-lane mask arithmetic, sequence sizes, a DPP row scan for the
-// output offsets.  Per-lane match lengths are capped at 36 bytes; only the LAST selected match of a
-// window (the one that can run past the window) is extended cooperatively.
+// DPP row shifts and the wave-wide inclusive scan built from them (used by the flush)
 __device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x, int d)
 {
     switch (d) {
@@ -223,7 +205,7 @@ __device__ __forceinline__ uint32_t ffbl(uint32_t x)
     return r;
 }
 // number of equal leading bytes (0..4) given x = a ^ b
-__device__ __forceinline__ uint32_t eq_bytes3(uint32_t x)
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t x)
 {
     const uint32_t t = ffbl(x) >> 3;  // x == 0 -> 0x1FFFFFFF
     return t < 4u ? t : 4u;
@@ -396,7 +378,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 // equal bytes of x1..x4: the first non-zero dword decides (all zero: 16 + 4 = 20, still matching)
                 const uint32_t t1 = x1 ? x1 : (x2 ? x2 : (x3 ? x3 : x4));
                 const uint32_t skip = x1 ? 4u : (x2 ? 8u : (x3 ? 12u : 16u));
-                const uint32_t lraw = skip + eq_bytes3(t1);
+                const uint32_t lraw = skip + eq_bytes(t1);
                 lenh = __builtin_amdgcn_inverse_ballot_w64(Hm) ? lraw : 0u;
                 Zm = ballot((x1 | x2 | x3 | x4) == 0u);
             }
