@@ -111,27 +111,83 @@ __global__ __launch_bounds__(256) void k_scan_u64(const unsigned long long *__re
     if (threadIdx.x == 0) out[n] = carry;
 }
 
-// copy n bytes src -> dst (dst arbitrary alignment, src 4-byte aligned) by one wave
-__device__ __forceinline__ void wg_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n)
+// copy n bytes src -> dst (dst arbitrary alignment, src 4-byte aligned) by one wave, in two phases so that a
+// caller can issue the loads of SEVERAL streams before the first store: the kernel is a latency chain (one wave per
+// block, a few hundred bytes per stream), so memory round trips per wave are what it costs.
+struct WaveCopy {
+    uint32_t a[4], b[4];  // first 1 KiB of the body: 4 dwords per lane
+    uint32_t edge;        // head byte (lanes < head) or tail byte (lanes 32.. < 32 + tail)
+    uint32_t head, nw, sh;
+    bool small;
+};
+
+__device__ __forceinline__ void wave_copy_load(WaveCopy &c, const uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                               uint32_t n)
 {
-    const uint32_t tid = threadIdx.x & 63u, nthr = 64u;
-    const uint32_t head = (uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
-    if (n < 16u + head) {
-        for (uint32_t i = tid; i < n; i += nthr) dst[i] = src[i];
+    const uint32_t tid = threadIdx.x & 63u;
+    c.head = (uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
+    c.small = n < 16u + c.head;
+    c.nw = c.small ? 0u : (n - c.head) >> 2;
+    c.sh = c.head & 3u;  // src byte offset of dst word 0 (src is aligned, head < 4)
+    c.edge = 0u;
+    if (c.small) {
+        if (tid < n) c.edge = src[tid];  // n < 19
         return;
     }
-    if (tid < head) dst[tid] = src[tid];
-    const uint32_t nw = (n - head) >> 2;
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
     const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-    const uint32_t sh = head & 3u;  // src byte offset of dst word 0 (src is aligned, head < 4)
     const uint32_t src_words = (n + 3u) >> 2;  // dwords of src that hold valid bytes
-    for (uint32_t w = tid; w < nw; w += nthr) {
-        uint32_t a = s32[w], b = (sh && w + 1u < src_words) ? s32[w + 1u] : 0u;
-        d32[w] = __builtin_amdgcn_alignbyte(b, a, sh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = (uint32_t)k * 64u + tid;
+        c.a[k] = w < c.nw ? s32[w] : 0u;
+        c.b[k] = (c.sh && w < c.nw && w + 1u < src_words) ? s32[w + 1u] : 0u;
     }
-    const uint32_t done = head + (nw << 2);
-    if (tid < n - done) dst[done + tid] = src[done + tid];
+    const uint32_t done = c.head + (c.nw << 2), tail = n - done;  // tail < 4
+    if (tid < c.head) c.edge = src[tid];
+    else if (tid >= 32u && tid - 32u < tail) c.edge = src[done + tid - 32u];
+}
+
+__device__ __forceinline__ void wave_copy_store(const WaveCopy &c, uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                uint32_t n)
+{
+    const uint32_t tid = threadIdx.x & 63u;
+    if (c.small) {
+        if (tid < n) dst[tid] = (uint8_t)c.edge;
+        return;
+    }
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + c.head);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = (uint32_t)k * 64u + tid;
+        if (w < c.nw) d32[w] = __builtin_amdgcn_alignbyte(c.b[k], c.a[k], c.sh);
+    }
+    const uint32_t done = c.head + (c.nw << 2), tail = n - done;
+    if (tid < c.head) dst[tid] = (uint8_t)c.edge;
+    else if (tid >= 32u && tid - 32u < tail) dst[done + tid - 32u] = (uint8_t)c.edge;
+    // streams longer than 1 KiB + head: the rest, 1 KiB per pass
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+    const uint32_t src_words = (n + 3u) >> 2;
+    for (uint32_t base = 256u; base < c.nw; base += 256u) {
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w = base + (uint32_t)k * 64u + tid;
+            a[k] = w < c.nw ? s32[w] : 0u;
+            b[k] = (c.sh && w < c.nw && w + 1u < src_words) ? s32[w + 1u] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w = base + (uint32_t)k * 64u + tid;
+            if (w < c.nw) d32[w] = __builtin_amdgcn_alignbyte(b[k], a[k], c.sh);
+        }
+    }
+}
+
+__device__ __forceinline__ void wg_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n)
+{
+    WaveCopy c;
+    wave_copy_load(c, dst, src, n);
+    wave_copy_store(c, dst, src, n);
 }
 
 __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_t *__restrict__ scratch,
@@ -193,9 +249,25 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
     const bool leftover = bsize != P.blocksize;
     const uint32_t ns = (P.split && !leftover) ? P.typesize : 1u;
     uint32_t q = bs;
+    // all stream sizes of the block in one load (lane j holds stream j; ns <= 16), broadcast per stream below
+    const uint64_t sidx0 = ((uint64_t)chunk * P.nblocks + b) * P.nwaves;
+    const uint32_t cs_l = lane < ns ? csize[sidx0 + lane] : 0u;
+    if (ns == 2u) {  // the genotype case (typesize 2): both planes' loads in flight before the first store
+        const uint32_t cs0 = (uint32_t)__builtin_amdgcn_readlane((int)cs_l, 0), cs1 = (uint32_t)__builtin_amdgcn_readlane((int)cs_l, 1);
+        uint8_t *d0 = cdst + q + 4u, *d1 = d0 + cs0 + 4u;
+        const uint8_t *s0 = scratch + sidx0 * P.slot_bytes, *s1 = s0 + P.slot_bytes;
+        WaveCopy c0, c1;
+        wave_copy_load(c0, d0, s0, cs0);
+        wave_copy_load(c1, d1, s1, cs1);
+        if (lane < 4) cdst[q + lane] = (uint8_t)(cs0 >> (lane * 8));
+        else if (lane < 8) d0[cs0 + lane - 4u] = (uint8_t)(cs1 >> ((lane - 4u) * 8));
+        wave_copy_store(c0, d0, s0, cs0);
+        wave_copy_store(c1, d1, s1, cs1);
+        return;
+    }
     for (uint32_t j = 0; j < ns; ++j) {
-        const uint64_t sidx = ((uint64_t)chunk * P.nblocks + b) * P.nwaves + j;
-        const uint32_t cs = csize[sidx];
+        const uint64_t sidx = sidx0 + j;
+        const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cs_l, (int)j);
         if (lane < 4) cdst[q + lane] = (uint8_t)(cs >> (lane * 8));
         wg_copy(cdst + q + 4u, scratch + sidx * P.slot_bytes, cs);
         q += 4u + cs;
