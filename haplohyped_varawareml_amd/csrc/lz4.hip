@@ -417,7 +417,11 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 LNG &= ballot(len < maxlen);               // clipped at the end of the stream: not "long"
                 len = len < maxlen ? len : maxlen;
             }
-            // ---- greedy parse: the only serial part (scalar unit; 8 scalar instructions + one v_readlane per match)
+            // ---- greedy parse: the only serial part (scalar unit; 8 scalar instructions + one v_readlane per match).
+            //      Probe builds (-DLZ_PROBE_SALU / -DLZ_PROBE_VALU: 16 extra independent s_mov / v_add per window) cost
+            //      +14 % / +6 % kernel time: a wave's own serial instruction stream is the limit.  A variant with a
+            //      per-lane precomputed "candidates after my match" mask (4 scalar + 2 v_readlane per match) was
+            //      slower (36.5 vs 35.4 ms): the readlane -> compare -> branch chain is longer than this one.
             unsigned long long SEL, mrest;
             uint32_t lcur, last;
             asm volatile("s_mov_b64 %[sel], 0\n\t"
@@ -474,6 +478,15 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             }
             // next window's own bytes: request now, consumed after the enqueue below
             const uint32_t np = p + (lcur > 64u ? lcur : 64u);
+#ifdef LZ_PROBE_SALU  // sensitivity probe (development builds only): 16 extra scalar instructions per window
+            asm volatile(".rept 16\n\ts_mov_b32 s100, 0\n\t.endr" ::: "s100");
+#endif
+#ifdef LZ_PROBE_VALU  // ... or 16 extra vector instructions per window
+            {
+                uint32_t pv = lane;
+                asm volatile(".rept 16\n\tv_add_u32 %0, 1, %0\n\t.endr" : "+v"(pv));
+            }
+#endif
             const Own6 nown = lds_load6(in, np + lane);
             const uint32_t npbv = (uint32_t)in[np + lane - 1u];
             // ---- enqueue the selected matches; layout + emission happen once per ~12 windows (flush), one
