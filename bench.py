@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--blocksize", type=int, default=dev.DEFAULT_BLOCKSIZE, help="Blosc2 block bytes")
     ap.add_argument("--clevel", type=int, default=5, help="codec level (reference: 5); 1-2 = run-only fast mode")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encode/compress overlap")
+    ap.add_argument("--lookahead", type=int, default=1, help="shards the encode stream runs ahead of the compress stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one GPU in rehearsals")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
@@ -89,7 +90,7 @@ def build_shards(ctx, args, rank, world):
     return shards
 
 
-def one_step(ctx, shards, S, blocksize, streams=None):
+def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
     """encode + pad + compress of every shard.  With two streams the (issue-bound) LZ4 kernel of shard k
     overlaps the (HBM-bound) index/encode kernels of shard k+1 — the same software pipeline the streaming
     converter uses; every kernel still runs once per shard per step."""
@@ -101,18 +102,32 @@ def one_step(ctx, shards, S, blocksize, streams=None):
                          dst=sh.dst, chunk_off=sh.off, sync=False)
         return
     s_enc, s_cmp = streams
-    for sh in shards:
+
+    def enc(sh):
         with torch.cuda.stream(s_enc):
             if sh.cmp_done is not None:
                 s_enc.wait_event(sh.cmp_done)          # G of this shard is free again
             ctx.encode_text(sh.text, S, region=sh.contig, v_base=0, out=sh.res)
             ctx.pad_tail(sh.res)
-            ready = s_enc.record_event()
+            sh.ready = s_enc.record_event()
+
+    def cmp_(sh):
         with torch.cuda.stream(s_cmp):
-            s_cmp.wait_event(ready)
+            s_cmp.wait_event(sh.ready)
             ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2,
                          dst=sh.dst, chunk_off=sh.off, sync=False)
             sh.cmp_done = s_cmp.record_event()
+
+    # hhgt_encode_text blocks the host (it returns counts).  With `lookahead` shards encoded ahead, the compress of
+    # shard k is queued BEFORE the host blocks in the encode of shard k + lookahead, so the compress stream always
+    # has its next kernel waiting and the encode chain's launch gaps never sit between two LZ4 kernels.
+    n = len(shards)
+    for i in range(min(lookahead, n)):
+        enc(shards[i])
+    for k in range(n):
+        cmp_(shards[k])
+        if k + lookahead < n:
+            enc(shards[k + lookahead])
 
 
 def cpu_baseline(ctx, shards, S, target_s, extended=False):
@@ -226,7 +241,7 @@ def main():
     # of the previous shard do not starve them of LDS
     streams = None if args.no_overlap else (torch.cuda.Stream(priority=-1), torch.cuda.Stream())
     for _ in range(args.warmup):
-        one_step(ctx, shards, S, args.blocksize, streams)
+        one_step(ctx, shards, S, args.blocksize, streams, args.lookahead)
     barrier()
     ctx.profile(True)
     # one un-timed single-stream pass: clean per-stage device times (with two streams the event pairs of the
@@ -239,7 +254,7 @@ def main():
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(ctx, shards, S, args.blocksize, streams)
+        one_step(ctx, shards, S, args.blocksize, streams, args.lookahead)
     barrier()
     dt = time.perf_counter() - t0
     stages = ctx.profile_read()

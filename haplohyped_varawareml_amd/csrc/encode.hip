@@ -39,6 +39,7 @@ __device__ __forceinline__ uint32_t parse_field(uint32_t x)
 }
 
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x4_al __attribute__((ext_vector_type(4)));
 
 #define FILL_FIELD 0x09307C30u  // "0|0\t"
 #ifndef TILE_G
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
             if (valid && nval) {
                 const uint64_t off = (uint64_t)soff + 4ull * ls;
                 if (nval == 4u && off + 16ull <= n) {
-                    u32x4_unaligned t = *reinterpret_cast<const u32x4_unaligned *>(text + off);
+                    u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
                     v = make_uint4(t.x, t.y, t.z, t.w);
                 } else {
                     uint32_t d[4];
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
         const uint32_t sin = s - scol * lay.Sc;
         int8_t *dst = G + ((((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull) + c16 * 16u;
         if (kfirst >= 0) {
-            *reinterpret_cast<uint4 *>(dst) = v;
+            __builtin_nontemporal_store(u32x4_al{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_al *>(dst));
         } else if (kfirst + 8 > 0) {  // tile straddles v_base: keep the columns the previous batch wrote
             uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll

@@ -18,6 +18,7 @@
 #include "common.h"
 
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t nl_mask4(uint32_t x)
 {
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
         uint64_t g0 = rbase + (uint64_t)it * 1024u + lane * 16u;
         uint32_t m = 0;
         if (g0 + 16 <= n) {
-            uint4 v = *reinterpret_cast<const uint4 *>(text + g0);
+            const u32x4_t v4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(text + g0));  // streamed once
+            uint4 v = make_uint4(v4.x, v4.y, v4.z, v4.w);
             m = nl_mask4(v.x) | (nl_mask4(v.y) << 4) | (nl_mask4(v.z) << 8) | (nl_mask4(v.w) << 12);
         } else if (g0 <= n) {
             for (int j = 0; j < 16; ++j) {
