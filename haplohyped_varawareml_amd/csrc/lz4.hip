@@ -20,6 +20,7 @@
 // Algorithmic bytes = blocksize read + compressed bytes written per block; measured: the kernel is bound by
 // instruction issue, not by HBM.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #define LZ_MINMATCH 4u
@@ -636,8 +637,11 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
         return by_lds < by_waves ? by_lds : by_waves;
     };
     uint32_t hashlog = 12;
+    // (HHGT_LZ4_MINWAVES=8 HHGT_LZ4_HASHLOG=7 gives 16 workgroups per CU: LZ4 alone 35.3 -> 34.5 ms, but the whole
+    //  two-stream step does not move (53.3 ms) because the index kernel then finds no room beside it; on genotype
+    //  planes the ratio is the same 4.326 with 64 .. 512 table entries)
     while (hashlog > 9 && occ(hashlog) < occ(9)) --hashlog;
-    if (hl_env >= 8 && hl_env <= 13) hashlog = (uint32_t)hl_env;
+    if (hl_env >= 6 && hl_env <= 13) hashlog = (uint32_t)hl_env;
     // HHGT_LZ4_LDSPAD: extra dynamic LDS per workgroup — an experiment knob that caps how many LZ4 workgroups
     // share a CU, leaving LDS for the HBM-bound kernels of the other stream
     static const size_t lds_pad = getenv("HHGT_LZ4_LDSPAD") ? (size_t)atoi(getenv("HHGT_LZ4_LDSPAD")) : 0;
@@ -665,6 +669,14 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     }
     static const int mw_env = getenv("HHGT_LZ4_MINWAVES") ? atoi(getenv("HHGT_LZ4_MINWAVES")) : 7;
     const int mw = nwaves <= 2 ? mw_env : 0;
+    static const bool dbg = getenv("HHGT_LZ4_DEBUG") != nullptr;
+    if (dbg) {  // development: what the runtime thinks fits on a CU
+        int n7 = -1, n8 = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n7, k_lz4_blocks<7, 6>, (int)(64u * nwaves), lds);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, k_lz4_blocks<8, 6>, (int)(64u * nwaves), lds);
+        fprintf(stderr, "[hhgt lz4] nwaves=%u hashlog=%u lds=%zu B/workgroup, workgroups per CU: <7,6> %d  <8,6> %d\n", nwaves, hashlog,
+                lds, n7, n8);
+    }
 #define LZ_LAUNCH(MWV, ALG)                                                                                          \
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
