@@ -1,0 +1,229 @@
+"""Minimal native HDF5 writer: just enough of the file format to hold what the converter produces.
+
+The reference writes its output through h5py + hdf5plugin (`/root/reference/src/haplohyped/vcf_to_h5.py:131-135`:
+`create_dataset(..., compression=32001, compression_opts=(2,2,0,0,5,1,2), chunks=True)`, merged into
+`OUT/{cohort}.h5` at :154-180).  Neither library exists in this image, and the chunks are produced on the GPU
+already in their final, filtered form — so this module lays the file out itself, the way
+`dset.id.write_direct_chunk` would: chunk bytes are appended as they arrive, the metadata (object headers, group
+and chunk B-trees, heaps) follows at close, the superblock at offset 0 last.
+
+Format subset (HDF5 File Format Specification, "version 0/1" structures, readable by every libhdf5 >= 1.6):
+superblock v0; groups as symbol tables (object header v1 + local heap + v1 B-tree + symbol nodes); datasets with
+dataspace v1, datatype v1 (fixed-point, fixed-length string), fill value v2, layout v3 (contiguous, or chunked
+with a v1 chunk B-tree) and filter pipeline v1.  Filter 32001 is the registered id of the Blosc filter
+(hdf5plugin.Blosc / hdf5-blosc): its chunk payload is a Blosc-1 chunk with the 16-byte header — the form this
+repository pins bit-exactly against c-blosc 1.21 (oracle/codec_oracle.c, tests/test_oracle_codec.py).
+
+Verified in tests/test_h5file.py with the image's independent libhdf5 1.10.6 (h5py 3.3 under /opt/conda,
+when present): structure, dtypes, shapes, chunk index and raw chunk bytes (`read_direct_chunk`).
+"""
+import struct
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+SIG = b"\x89HDF\r\n\x1a\n"
+LEAF_K = 16        # symbol-table node holds up to 2 * LEAF_K entries
+GROUP_K = 16       # group B-tree node holds up to 2 * GROUP_K children
+CHUNK_K = 32       # chunk B-tree node holds up to 2 * CHUNK_K children (the library's default for superblock v0)
+FILTER_BLOSC = 32001
+
+
+def _pad8(b):
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _msg(mtype, data, flags=0):
+    data = _pad8(data)
+    return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+
+def _datatype(dt):
+    dt = np.dtype(dt)
+    if dt.kind in "iu":
+        bits0 = 0x08 if dt.kind == "i" else 0x00            # little endian, zero padding, signed flag
+        return struct.pack("<BBBBI", 0x10, bits0, 0, 0, dt.itemsize) + struct.pack("<HH", 0, dt.itemsize * 8)
+    if dt.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, dt.itemsize)   # null-padded ASCII, as numpy 'S'
+    raise TypeError(f"h5file: unsupported dtype {dt}")
+
+
+def _dataspace(shape):
+    return struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", int(d)) for d in shape)
+
+
+def _object_header(messages):
+    body = b"".join(messages)
+    return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body
+
+
+class H5Writer:
+    """Append-only writer.  Usage:
+        w = H5Writer(path); addr = w.append(chunk_bytes) ...; w.add_chunked(...); w.add_array(...); w.close()"""
+
+    def __init__(self, path):
+        self.f = open(path, "wb")
+        self.f.write(b"\0" * 2048)            # superblock goes here at close
+        self.pos = 2048
+        self.groups = {"/": {}}              # group path -> {name: ("group", path) | ("dataset", header_addr)}
+
+    # ---- raw space ------------------------------------------------------------------------------------------
+    def append(self, data, align=8):
+        pad = -self.pos % align
+        if pad:
+            self.f.write(b"\0" * pad)
+            self.pos += pad
+        addr = self.pos
+        self.f.write(memoryview(data))
+        self.pos += len(data)
+        return addr
+
+    # ---- tree of names -----------------------------------------------------------------------------------------
+    def _ensure_group(self, path):
+        if path in self.groups:
+            return
+        parent, _, name = path.rstrip("/").rpartition("/")
+        parent = parent or "/"
+        self._ensure_group(parent)
+        self.groups[path] = {}
+        self.groups[parent][name] = ("group", path)
+
+    def _link(self, group, name, header_addr):
+        group = "/" + group.strip("/") if group.strip("/") else "/"
+        self._ensure_group(group)
+        if name in self.groups[group]:
+            raise ValueError(f"h5file: {group}/{name} exists")
+        self.groups[group][name] = ("dataset", header_addr)
+
+    # ---- datasets -------------------------------------------------------------------------------------------------
+    def add_array(self, group, name, arr):
+        """contiguous, unfiltered dataset holding `arr` (ints or fixed-length byte strings)"""
+        arr = np.ascontiguousarray(arr)
+        data_addr = self.append(arr.tobytes()) if arr.nbytes else UNDEF
+        msgs = [
+            _msg(0x0001, _dataspace(arr.shape)),
+            _msg(0x0003, _datatype(arr.dtype), flags=1),
+            _msg(0x0005, struct.pack("<BBBB", 2, 2, 0, 0)),                          # fill value: late alloc, undefined
+            _msg(0x0008, struct.pack("<BBQQ", 3, 1, data_addr, arr.nbytes)),          # layout v3, contiguous
+        ]
+        self._link(group, name, self.append(_object_header(msgs)))
+
+    def add_chunked(self, group, name, shape, dtype, chunk_shape, chunks, filter_id=None, cd_values=(), filter_name=b""):
+        """chunks: iterable of (offsets tuple in elements, file address, stored size in bytes[, filter mask]); every
+        chunk of the grid must be present (the converter always writes full grids)."""
+        dt = np.dtype(dtype)
+        rank = len(shape)
+        assert len(chunk_shape) == rank
+        ents = sorted((tuple(int(o) for o in c[0]) + (0,), int(c[1]), int(c[2]), int(c[3]) if len(c) > 3 else 0) for c in chunks)
+        upper = tuple(-(-int(shape[0]) // int(chunk_shape[0])) * int(chunk_shape[0]) if i == 0 else 0 for i in range(rank)) + (0,)
+        btree = self._chunk_btree(ents, rank, upper)
+        msgs = [
+            _msg(0x0001, _dataspace(shape)),
+            _msg(0x0003, _datatype(dt), flags=1),
+            _msg(0x0005, struct.pack("<BBBB", 2, 3, 0, 0)),                          # fill value: incremental alloc
+        ]
+        if filter_id is not None:
+            nm = _pad8(filter_name + b"\0") if filter_name else b""
+            cd = b"".join(struct.pack("<I", int(v) & 0xFFFFFFFF) for v in cd_values)
+            if len(cd_values) % 2:
+                cd += b"\0\0\0\0"
+            msgs.append(_msg(0x000B, struct.pack("<BB6x", 1, 1) + struct.pack("<HHHH", filter_id, len(nm), 0, len(cd_values)) + nm + cd,
+                             flags=1))
+        lay = struct.pack("<BBBQ", 3, 2, rank + 1, btree) + b"".join(struct.pack("<I", int(c)) for c in chunk_shape) + \
+            struct.pack("<I", dt.itemsize)
+        msgs.append(_msg(0x0008, lay))
+        self._link(group, name, self.append(_object_header(msgs)))
+
+    def _chunk_btree(self, ents, rank, upper):
+        """v1 B-tree, node type 1 (raw data chunks): key = (stored size u32, filter mask u32, offsets u64 x (rank+1))"""
+        if not ents:
+            return UNDEF
+
+        def key(off, size=0, mask=0):
+            return struct.pack("<II", size, mask) + b"".join(struct.pack("<Q", o) for o in off)
+
+        keysize = 8 + 8 * (rank + 1)
+        node_bytes = 24 + (2 * CHUNK_K + 1) * keysize + 2 * CHUNK_K * 8
+        # level 0: (first key offsets, first key bytes, child address) per chunk
+        level = 0
+        items = [(e[0], key(e[0], e[2], e[3]), e[1]) for e in ents]
+        while True:
+            groups = [items[i:i + 2 * CHUNK_K] for i in range(0, len(items), 2 * CHUNK_K)]
+            # nodes of one level are laid out back to back so that sibling addresses are known up front
+            pad = -self.pos % 8
+            base = self.pos + pad
+            addrs = [base + i * node_bytes for i in range(len(groups))]
+            out = bytearray(b"\0" * pad)
+            nxt = []
+            for gi, g in enumerate(groups):
+                last = groups[gi + 1][0][0] if gi + 1 < len(groups) else upper
+                body = b"".join(k + struct.pack("<Q", a) for _, k, a in g) + key(last)
+                node = b"TREE" + struct.pack("<BBHQQ", 1, level, len(g), addrs[gi - 1] if gi else UNDEF,
+                                             addrs[gi + 1] if gi + 1 < len(groups) else UNDEF) + body
+                out += node + b"\0" * (node_bytes - len(node))
+                nxt.append((g[0][0], g[0][1], addrs[gi]))
+            self.f.write(out)
+            self.pos += len(out)
+            if len(groups) == 1:
+                return addrs[0]
+            items, level = nxt, level + 1
+
+    # ---- groups ---------------------------------------------------------------------------------------------------
+    def _write_group(self, path):
+        """-> (object header address, btree address, heap address) of the group at `path` (children first)"""
+        entries = []
+        for name, (kind, ref) in self.groups[path].items():
+            if kind == "group":
+                hdr, bt, hp = self._write_group(ref)
+                entries.append((name.encode(), hdr, 1, bt, hp))
+            else:
+                entries.append((name.encode(), ref, 0, 0, 0))
+        entries.sort(key=lambda e: e[0])
+        # local heap: offset 0 = "" (the B-tree's leftmost key), then the names
+        heap = bytearray(b"\0" * 8)
+        offs = []
+        for nm, *_ in entries:
+            offs.append(len(heap))
+            heap += _pad8(nm + b"\0")
+        heap_data = self.append(bytes(heap))
+        heap_addr = self.append(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), 1, heap_data))   # free list: H5HL_FREE_NULL
+        # symbol nodes of up to 2 * LEAF_K entries each
+        snods = []
+        for i in range(0, max(len(entries), 1), 2 * LEAF_K):
+            part = list(zip(entries[i:i + 2 * LEAF_K], offs[i:i + 2 * LEAF_K]))
+            body = b"".join(struct.pack("<QQI4xQQ", off, e[1], e[2], e[3] if e[2] else 0, e[4] if e[2] else 0) for e, off in part)
+            node = b"SNOD" + struct.pack("<BBH", 1, 0, len(part)) + body
+            node += b"\0" * (8 + 2 * LEAF_K * 40 - len(node))
+            snods.append((self.append(node), part[-1][1] if part else 0))
+        if len(snods) > 2 * GROUP_K:
+            raise ValueError(f"h5file: group {path} has too many entries for a single-level group B-tree")
+        body = struct.pack("<Q", 0) + b"".join(struct.pack("<QQ", a, last_off) for a, last_off in snods)
+        node = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods), UNDEF, UNDEF) + body
+        node += b"\0" * (24 + (2 * GROUP_K + 1) * 8 + 2 * GROUP_K * 8 - len(node))
+        bt_addr = self.append(node)
+        hdr = self.append(_object_header([_msg(0x0011, struct.pack("<QQ", bt_addr, heap_addr))]))
+        return hdr, bt_addr, heap_addr
+
+    def close(self):
+        hdr, bt, hp = self._write_group("/")
+        eof = self.pos
+        sb = SIG + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0) + struct.pack("<HHI", LEAF_K, GROUP_K, 0) + \
+            struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF) + struct.pack("<QQI4xQQ", 0, hdr, 1, bt, hp)
+        self.f.seek(0)
+        self.f.write(sb)
+        self.f.close()
+        self.f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.f is not None:
+            self.close()
+
+
+def blosc_cd_values(typesize, chunk_nbytes, clevel=5, shuffle=1, compcode=1):
+    """client data of filter 32001 as hdf5-blosc's set_local leaves it: [filter revision 2, Blosc format 2, typesize,
+    uncompressed chunk bytes, clevel, shuffle, compressor (1 = LZ4; the reference passes 2 = LZ4HC — same block
+    format, and the header of each chunk says which decoder family it needs)]"""
+    return (2, 2, int(typesize), int(chunk_nbytes), int(clevel), int(shuffle), int(compcode))

@@ -24,13 +24,15 @@ assert SNP_DTYPE.itemsize == 35
 
 
 class StoreWriter:
-    def __init__(self, path, samples, sc, vc, typesize=2, cohort_name="", donor_ids=None):
+    def __init__(self, path, samples, sc, vc, typesize=2, cohort_name="", donor_ids=None, chunk_format="blosc2"):
         self.path = path
         os.makedirs(path, exist_ok=True)
+        assert chunk_format in ("blosc1", "blosc2")
         self.meta = dict(format="hhgt-store", version=1, cohort_name=cohort_name, samples=list(samples),
                          donor_ids=list(donor_ids) if donor_ids is not None else list(samples),
                          sc=int(sc), vc=int(vc), typesize=int(typesize), blocksize=min(int(vc) * 2, 8192),
-                         codec="blosc2: byte-shuffle + LZ4 block format", groups={})
+                         chunk_format=chunk_format,
+                         codec=f"{chunk_format}: byte-shuffle + LZ4 block format", groups={})
         self._cur = None
 
     def begin_group(self, group):
@@ -140,3 +142,60 @@ class GenotypeStore:
         rec["phase1"] = ph[:, 0]
         rec["phase2"] = ph[:, 1]
         return rec
+
+
+def export_h5(store_path, h5_path):
+    """store directory -> one HDF5 file at the reference's output path (`OUT/{cohort}.h5`,
+    /root/reference/src/haplohyped/vcf_to_h5.py:161), written natively (h5file.py; no h5py in this image):
+
+        /samples, /donor_ids                         fixed-length strings
+        /chr_{N}/genotype   int8 [S, V', 2]          chunks (sc, vc, 2), filter 32001 (Blosc): the stored chunk bytes
+                                                     ARE the store's chunks, copied once in bulk
+        /chr_{N}/start, stop   uint32 [V']           0-based start, stop = start + 1 (vcfpp.h:1118-1127, SNPs)
+        /chr_{N}/ref, alt      S1 [V']
+        /chr_{N}/chrom_run_first, chrom_run_name     CHROM value runs (first variant index, name)
+
+    The reference's layout (S x 22 groups `donor_{id}/chr_{N}` of 35-byte compound records) is what
+    GenotypeStore.snp_records / VCFH5Reader synthesise on demand; here every genotype is stored once.
+    Needs Blosc-1 framed chunks (filter 32001 is hdf5-blosc / hdf5plugin.Blosc): stores written with
+    chunk_format="blosc1", which is what the converter does."""
+    from .h5file import FILTER_BLOSC, H5Writer, blosc_cd_values
+    meta = json.load(open(os.path.join(store_path, "meta.json")))
+    if meta.get("chunk_format", "blosc2") != "blosc1":
+        raise ValueError("export_h5: filter 32001 stores Blosc-1 chunks; this store holds " + meta.get("chunk_format", "blosc2"))
+    sc, vc, S = meta["sc"], meta["vc"], len(meta["samples"])
+
+    def strings(xs):
+        n = max([len(x.encode()) for x in xs] + [1])
+        return np.array([x.encode() for x in xs], dtype=f"S{n}")
+
+    with H5Writer(h5_path) as w:
+        w.add_array("/", "samples", strings(meta["samples"]))
+        w.add_array("/", "donor_ids", strings(meta["donor_ids"]))
+        for group, g in meta["groups"].items():
+            d = os.path.join(store_path, group)
+            off = np.load(os.path.join(d, "offsets.npy")).astype(np.uint64)
+            start = np.load(os.path.join(d, "start.npy"))
+            base = None
+            with open(os.path.join(d, "chunks.bin"), "rb") as f:      # one bulk copy of all chunk bytes
+                while True:
+                    buf = f.read(64 << 20)
+                    if not buf:
+                        break
+                    a = w.append(buf, align=8 if base is None else 1)
+                    base = a if base is None else base
+            base = w.pos if base is None else base
+            ids = np.arange(len(off) - 1)
+            vcol, scol = ids // g["n_scol"], ids % g["n_scol"]
+            chunks = [((int(sci) * sc, int(vci) * vc, 0), base + int(o0), int(o1 - o0))
+                      for sci, vci, o0, o1 in zip(scol, vcol, off[:-1], off[1:])]
+            w.add_chunked(group, "genotype", (S, g["n_variants"], 2), np.int8, (sc, vc, 2), chunks, filter_id=FILTER_BLOSC,
+                          cd_values=blosc_cd_values(meta["typesize"], sc * vc * 2), filter_name=b"blosc")
+            w.add_array(group, "start", start.astype(np.uint32))
+            w.add_array(group, "stop", (start + 1).astype(np.uint32))
+            w.add_array(group, "ref", np.load(os.path.join(d, "ref.npy")).astype(np.uint8).view("S1"))
+            w.add_array(group, "alt", np.load(os.path.join(d, "alt.npy")).astype(np.uint8).view("S1"))
+            runs = json.load(open(os.path.join(d, "chrom_runs.json")))
+            w.add_array(group, "chrom_run_first", np.array([r[0] for r in runs], np.uint32))
+            w.add_array(group, "chrom_run_name", strings([r[1] for r in runs]) if runs else np.zeros(0, "S1"))
+    return h5_path

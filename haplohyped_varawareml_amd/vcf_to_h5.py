@@ -6,8 +6,9 @@ class VCFtoHDF5Converter(cohort_name, vcf_dir, out_dir, sample_list_path, cores,
 input naming DIR/chr{N}.filtered.vcf.gz (:151), contig chr{N} (:98), groups chr_{N} (:132).
 Different inside: one device pass per chromosome FILE encodes every sample (the reference makes
 len(donors) x 22 passes, :142-152,191-192), the genotypes are stored once as a cohort matrix of
-Blosc2-framed chunks (store.py) instead of S x 22 compound datasets, and failures are not swallowed
-(the reference drops worker exceptions, :191-192,204-205).
+Blosc-framed chunks (store.py: the working store; h5file.py: the same chunks as `OUT/{cohort}.h5`, an HDF5 file
+with filter-32001 datasets written without h5py) instead of S x 22 compound datasets, and failures are not
+swallowed (the reference drops worker exceptions, :191-192,204-205).
 """
 import logging
 import os
@@ -47,8 +48,14 @@ class VCFtoHDF5Converter:
     def store_path(self):
         return os.path.join(self.out_dir, f"{self.cohort_name}.hhgt")
 
+    @property
+    def h5_path(self):
+        """the reference's output file (vcf_to_h5.py:161)"""
+        return os.path.join(self.out_dir, f"{self.cohort_name}.h5")
+
     def genotype_vcf_to_store(self, ctx, writer, data_path: str, chromosome: int):
         """one chromosome file -> group chr_{N} (all samples at once)"""
+        from .device import BLOSC1      # filter 32001 = hdf5-blosc: Blosc-1 chunk framing
         from .pipeline import stream_file
         group = f"chr_{chromosome}"
         state = {"begun": False}
@@ -70,7 +77,7 @@ class VCFtoHDF5Converter:
 
         fs = stream_file(ctx, data_path, region=f"chr{chromosome}", sc=writer.meta["sc"], vc=writer.meta["vc"],
                          n_threads=self.cores or 0, on_header=on_header, on_columns=on_columns,
-                         on_variants=writer.add_variants)
+                         on_variants=writer.add_variants, fmt=BLOSC1)
         writer.add_chrom_runs(fs.chrom_runs)
         writer.end_group()
         self.stats[group] = fs
@@ -85,11 +92,11 @@ class VCFtoHDF5Converter:
 
     def run(self):
         from .device import Context, DEFAULT_SC, DEFAULT_VC
-        from .store import StoreWriter
+        from .store import StoreWriter, export_h5
         t0 = time.time()
         ctx = Context(0)
         writer = StoreWriter(self.store_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=self.cohort_name,
-                             donor_ids=[d for d in self.donor_ids if d])
+                             donor_ids=[d for d in self.donor_ids if d], chunk_format="blosc1")
         try:
             for chromosome in self.chromosomes:
                 vcf_file = os.path.join(self.vcf_dir, f"chr{chromosome}.filtered.vcf.gz")
@@ -101,6 +108,7 @@ class VCFtoHDF5Converter:
                             f"({fs.n_lines / max(fs.seconds, 1e-9):.0f} lines/s), ratio "
                             f"{fs.raw_bytes / max(fs.compressed_bytes, 1):.2f}")
             writer.close()
+            export_h5(self.store_path, self.h5_path)      # OUT/{cohort}.h5, readable by h5py + hdf5plugin
             logger.info(f"Total time taken: {time.time() - t0:.2f} seconds")
         finally:
             ctx.close()

@@ -1,6 +1,7 @@
 """-m gpu: files -> reader -> device pipeline -> store, through the reference's own surfaces
 (parse_vcf.VCFLoader, VCFtoHDF5Converter, VCFH5Reader), against the oracle and the golden vectors."""
 import gzip
+import json
 import os
 import shutil
 
@@ -9,6 +10,7 @@ import pytest
 import torch
 
 from oracle import oracle
+from tests import extlibs
 from haplohyped_varawareml_amd import synth
 from haplohyped_varawareml_amd.reader import write_bgzf
 
@@ -86,10 +88,29 @@ def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
         assert np.array_equal(r4["start"], o4["start"]) and b"".join(r4["ref"].tolist()) == bytes(o4["ref"])
     with pytest.raises(KeyError):
         rd.fetch_genotypes(conv.donor_ids[0], 5)
-    # every stored chunk is a Blosc2 frame the oracle decodes to the chunk-tiled matrix bytes
+    # every stored chunk is a Blosc-1 frame (filter 32001) the oracle decodes to the chunk-tiled matrix bytes
     off = np.load(os.path.join(store, "chr_22", "offsets.npy"))
     raw = np.fromfile(os.path.join(store, "chr_22", "chunks.bin"), dtype=np.uint8)
+    assert raw[0] == 2 and raw[3] == 2                      # Blosc-1 format version, typesize 2
     back = oracle.blosc_decompress(raw[off[0]:off[1]])
     assert back.size == 64 * 8192 * 2
     assert np.array_equal(back.view(np.int8).reshape(64, 8192, 2)[:3, :1000], G22)
     assert not back.view(np.int8).reshape(64, 8192, 2)[3:].any()
+    if extlibs.have_blosc():
+        assert np.array_equal(extlibs.blosc1_decompress(raw[off[0]:off[1]], back.size), back)
+    # ... and OUT/{cohort}.h5 (the reference's output path, vcf_to_h5.py:161) is an HDF5 file that an independent
+    # libhdf5 opens: same groups, tables, and the very same chunk bytes behind filter 32001
+    assert conv.h5_path == str(tmp_path / "out" / "test_cohort.h5") and os.path.exists(conv.h5_path)
+    from tests.test_h5file import h5check, have_h5py
+    if have_h5py():
+        got = h5check(conv.h5_path, tmp_path, "chr_22/genotype", "chr_4/genotype")
+        assert [x.decode() for x in got["samples"]] == names
+        meta = json.loads(str(got["chr_22/genotype|meta"]))
+        assert meta["shape"] == [3, 1000, 2] and meta["chunks"] == [64, 8192, 2] and meta["filters"][0][0] == 32001
+        assert meta["filters"][0][2][:4] == [2, 2, 2, 64 * 8192 * 2] and meta["n_chunks"] == 1
+        assert np.array_equal(got["chr_22/genotype|chunk|0,0,0"], raw[off[0]:off[1]])
+        assert int(got["chr_22/start"][0]) == 10012121 and np.array_equal(got["chr_22/stop"], got["chr_22/start"] + 1)
+        assert np.array_equal(got["chr_4/start"], o4["start"]) and got["chr_4/ref"].tobytes() == bytes(o4["ref"])
+        ck4 = oracle.blosc_decompress(got["chr_4/genotype|chunk|0,0,0"]).view(np.int8).reshape(64, 8192, 2)
+        assert np.array_equal(ck4[:3, :o4["n_kept"]], o4["G"])
+        assert [x.decode() for x in got["chr_4/chrom_run_name"]] == ["chr4"] and list(got["chr_4/chrom_run_first"]) == [0]

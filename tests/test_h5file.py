@@ -1,0 +1,120 @@
+"""CPU: the native HDF5 writer (haplohyped_varawareml_amd/h5file.py) against an independent reader — the image's
+libhdf5 1.10.6 through h5py 3.3 in /opt/conda (an interpreter this test only shells out to; when it is absent the
+library-backed checks skip and only the self-contained ones run)."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from haplohyped_varawareml_amd import h5file
+
+CONDA_PY = "/opt/conda/bin/python3.9"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def have_h5py():
+    if not os.path.exists(CONDA_PY):
+        return False
+    return subprocess.run([CONDA_PY, "-c", "import h5py"], capture_output=True).returncode == 0
+
+
+needs_h5py = pytest.mark.skipif(not have_h5py(), reason="no independent HDF5 library in this environment")
+
+
+def h5check(path, tmp_path, *dump):
+    out = str(tmp_path / "check.npz")
+    r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5check.py"), path, out, *dump], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def test_superblock_and_alignment(tmp_path):
+    p = str(tmp_path / "a.h5")
+    with h5file.H5Writer(p) as w:
+        w.add_array("/", "x", np.arange(5, dtype=np.uint32))
+    b = open(p, "rb").read()
+    assert b[:8] == b"\x89HDF\r\n\x1a\n" and b[8] == 0 and b[13] == 8 and b[14] == 8
+    eof = struct.unpack_from("<Q", b, 40)[0]
+    assert eof == len(b)
+    root_hdr = struct.unpack_from("<Q", b, 56 + 8)[0]
+    assert root_hdr % 8 == 0 and b[root_hdr] == 1          # object header version 1
+    with pytest.raises(ValueError):
+        w2 = h5file.H5Writer(str(tmp_path / "b.h5"))
+        w2.add_array("/", "x", np.zeros(1, np.uint8))
+        w2.add_array("/", "x", np.zeros(1, np.uint8))
+
+
+@needs_h5py
+def test_groups_arrays_and_strings(tmp_path):
+    p = str(tmp_path / "g.h5")
+    rng = np.random.default_rng(1)
+    want = {}
+    with h5file.H5Writer(p) as w:
+        for i in range(45):                                   # more than one symbol node (32 entries each)
+            a = rng.integers(0, 1 << 31, 7 + i, dtype=np.int64).astype([np.uint32, np.int8, np.uint8, np.int64, np.uint16][i % 5])
+            w.add_array("many", f"d{i:02d}", a)
+            want[f"many/d{i:02d}"] = a
+        s = np.array([b"NA12878", b"HG00096", b"x"], dtype="S7")
+        w.add_array("/", "samples", s)
+        want["samples"] = s
+        w.add_array("a/b/c", "deep", np.arange(6, dtype=np.uint32).reshape(2, 3))
+        want["a/b/c/deep"] = np.arange(6, dtype=np.uint32).reshape(2, 3)
+        w.add_array("a", "empty", np.zeros(0, np.uint32))
+        want["a/empty"] = np.zeros(0, np.uint32)
+    got = h5check(p, tmp_path)
+    names = dict(json.loads(str(got["|names"])))
+    assert names["many"] is False and names["a/b/c"] is False and names["a/b/c/deep"] is True
+    for k, a in want.items():
+        assert got[k].dtype == a.dtype and got[k].shape == a.shape and np.array_equal(got[k], a), k
+
+
+@needs_h5py
+@pytest.mark.parametrize("n_v_chunks", [1, 3, 70, 5000])        # 1 leaf; several; two levels (> 64); three levels (> 4096)
+def test_chunked_dataset_index(tmp_path, n_v_chunks):
+    p = str(tmp_path / "c.h5")
+    S, vc = 100, 4
+    V = n_v_chunks * vc - 1
+    rng = np.random.default_rng(n_v_chunks)
+    G = rng.integers(-9, 3, (S, V, 2), dtype=np.int8)
+    chunks = []
+    with h5file.H5Writer(p) as w:
+        for si in range(0, S, 64):
+            for vi in range(0, V, vc):
+                blk = np.zeros((64, vc, 2), np.int8)
+                sub = G[si:si + 64, vi:vi + vc]
+                blk[:sub.shape[0], :sub.shape[1]] = sub
+                chunks.append(((si, vi, 0), w.append(blk.tobytes()), blk.nbytes))
+        rng.shuffle(chunks)                                   # the writer sorts
+        w.add_chunked("chr_22", "genotype", (S, V, 2), np.int8, (64, vc, 2), chunks)
+    got = h5check(p, tmp_path)
+    meta = json.loads(str(got["chr_22/genotype|meta"]))
+    assert meta["shape"] == [S, V, 2] and meta["dtype"] == "int8" and meta["chunks"] == [64, vc, 2] and meta["filters"] == []
+    assert np.array_equal(got["chr_22/genotype"], G)
+
+
+@needs_h5py
+def test_filter_32001_message_and_raw_chunks(tmp_path):
+    p = str(tmp_path / "f.h5")
+    rng = np.random.default_rng(3)
+    payload = {}
+    with h5file.H5Writer(p) as w:
+        chunks = []
+        for si in (0, 64):
+            for vi in (0, 8192, 16384):
+                raw = rng.integers(0, 256, int(rng.integers(20, 400)), dtype=np.uint8).tobytes()
+                payload[(si, vi, 0)] = raw
+                chunks.append(((si, vi, 0), w.append(raw, align=1), len(raw)))
+        w.add_chunked("chr_1", "genotype", (100, 20000, 2), np.int8, (64, 8192, 2), chunks, filter_id=h5file.FILTER_BLOSC,
+                      cd_values=h5file.blosc_cd_values(2, 64 * 8192 * 2), filter_name=b"blosc")
+    got = h5check(p, tmp_path, "chr_1/genotype")
+    meta = json.loads(str(got["chr_1/genotype|meta"]))
+    assert meta["n_chunks"] == 6 and meta["chunks"] == [64, 8192, 2]
+    (fid, flags, cd, name), = meta["filters"]
+    assert fid == 32001 and cd == [2, 2, 2, 64 * 8192 * 2, 5, 1, 1] and name == "blosc"
+    for off, raw in payload.items():
+        key = ",".join(str(o) for o in off)
+        assert bytes(got["chr_1/genotype|chunk|" + key]) == raw and int(got["chr_1/genotype|mask|" + key]) == 0
