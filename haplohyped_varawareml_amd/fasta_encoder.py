@@ -112,7 +112,8 @@ class ReferenceGenome:
                                                    C.c_void_p(out.data_ptr()),
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         chunk_nbytes = CHUNK_ROWS * nch
-        dst, off, total = ctx.compress(out, chunk_nbytes, typesize=1, blocksize=32768)
+        from .device import BLOSC1      # filter 32001 = hdf5-blosc: Blosc-1 chunk framing
+        dst, off, total = ctx.compress(out, chunk_nbytes, typesize=1, blocksize=32768, fmt=BLOSC1)
         gdir = os.path.join(self.output_dir, chrom)
         os.makedirs(gdir, exist_ok=True)
         dst[:total].cpu().numpy().tofile(os.path.join(gdir, "chunks.bin"))
@@ -157,6 +158,28 @@ class ReferenceGenome:
         return out.view(torch.int8).view(-1, nch)[start - c0 * rows: end - c0 * rows]
 
 
+class HDF5Handler:
+    """the reference's class of the same name (fasta_encoder.py:120-141): all contigs into one HDF5 file,
+    `/{chrom}/sequence` behind filter 32001 — here laid out natively (h5file.py) from the chunks already on disk"""
+
+    @staticmethod
+    def save_to_hdf5(genome_df, hdf5_file):
+        from .h5file import FILTER_BLOSC, H5Writer, blosc_cd_values
+        logger.info(f"Saving entire reference genome to {hdf5_file}")
+        with H5Writer(hdf5_file) as w:
+            for chrom, gdir in sorted(dict(genome_df).items()):
+                meta = json.load(open(os.path.join(gdir, "meta.json")))
+                off = np.load(os.path.join(gdir, "offsets.npy")).astype(np.uint64)
+                base = w.append(np.fromfile(os.path.join(gdir, "chunks.bin"), dtype=np.uint8).tobytes())
+                nch, rows = len(meta["columns"]), meta["chunk_rows"]
+                chunks = [((i * rows, 0), base + int(off[i]), int(off[i + 1] - off[i])) for i in range(len(off) - 1)]
+                w.add_chunked(chrom, "sequence", (meta["length"], nch), np.int8, (rows, nch), chunks, filter_id=FILTER_BLOSC,
+                              cd_values=blosc_cd_values(1, rows * nch, shuffle=0), filter_name=b"blosc")
+                w.add_array(chrom, "columns", np.array([c.encode() for c in meta["columns"]], dtype="S1"))
+        logger.info(f"Successfully saved reference genome to {hdf5_file}")
+        return hdf5_file
+
+
 @click.command()
 @click.option("--fasta", required=True, type=click.Path(exists=True), help="Path to reference genome FASTA file")
 @click.option("--outdir", required=True, type=click.Path(), help="Path to results save folder")
@@ -168,6 +191,7 @@ def main(fasta, outdir, cores):
     ref_genome = ReferenceGenome(fasta_file=fasta, output_dir=store)
     done = ref_genome.load_genome_parallel()
     json.dump(dict(format="hhgt-reference", version=1, contigs=sorted(done)), open(os.path.join(store, "meta.json"), "w"))
+    HDF5Handler.save_to_hdf5(done, os.path.join(outdir, "reference_genome.h5"))      # fasta_encoder.py:195-200
     logger.info(f"Reference genome store created at {store}")
 
 

@@ -148,3 +148,19 @@ def test_dataset_reads_fasta_encoder_store(ctx, tmp_path, golden_dir):
     up = np.frombuffer(seq.upper(), dtype=np.uint8)
     assert np.array_equal(ds.reference_genome.host_bases("chr22"), up)
     ds.close()
+    # the reference's artefact name: OUT/reference_genome.h5 with /{chrom}/sequence behind filter 32001
+    h5 = str(tmp_path / "out" / "reference_genome.h5")
+    assert os.path.exists(h5)
+    from tests.test_h5file import h5check, have_h5py
+    if have_h5py():
+        import json
+        from oracle import oracle
+        got = h5check(h5, tmp_path, "chr22/sequence")
+        meta = json.loads(str(got["chr22/sequence|meta"]))
+        assert meta["shape"] == [len(seq), 5] and meta["dtype"] == "int8" and meta["filters"][0][0] == 32001
+        assert b"".join(got["chr22/columns"].tolist()) == b"ACGNT"
+        rows = meta["chunks"][0]
+        first = oracle.blosc_decompress(got["chr22/sequence|chunk|0,0"]).reshape(rows, 5)
+        want = np.zeros((rows, 5), np.uint8)
+        want[np.arange(rows), np.array([b"ACGNT".index(c) for c in up[:rows].tobytes()])] = 1
+        assert np.array_equal(first, want)
