@@ -9,7 +9,7 @@ and chunk B-trees, heaps) follows at close, the superblock at offset 0 last.
 
 Format subset (HDF5 File Format Specification, "version 0/1" structures, readable by every libhdf5 >= 1.6):
 superblock v0; groups as symbol tables (object header v1 + local heap + v1 B-tree + symbol nodes); datasets with
-dataspace v1, datatype v1 (fixed-point, fixed-length string), fill value v2, layout v3 (contiguous, or chunked
+dataspace v1, datatype v1 (fixed-point, fixed-length string, compound of those), fill value v2, layout v3 (contiguous, or chunked
 with a v1 chunk B-tree) and filter pipeline v1.  Filter 32001 is the registered id of the Blosc filter
 (hdf5plugin.Blosc / hdf5-blosc): its chunk payload is a Blosc-1 chunk with the 16-byte header — the form this
 repository pins bit-exactly against c-blosc 1.21 (oracle/codec_oracle.c, tests/test_oracle_codec.py).
@@ -45,6 +45,15 @@ def _datatype(dt):
         return struct.pack("<BBBBI", 0x10, bits0, 0, 0, dt.itemsize) + struct.pack("<HH", 0, dt.itemsize * 8)
     if dt.kind == "S":
         return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, dt.itemsize)   # null-padded ASCII, as numpy 'S'
+    if dt.kind == "V" and dt.names:
+        # compound, datatype version 1: per member name (padded to 8), byte offset, 28 bytes of (unused) array
+        # dimension fields, member datatype.  Packed layouts like the reference's 35-byte record
+        # (vcf_to_h5.py:119-127) keep their numpy offsets.
+        body = b""
+        for name in dt.names:
+            mt, moff = dt.fields[name][0], dt.fields[name][1]
+            body += _pad8(name.encode() + b"\0") + struct.pack("<IB3xI4x16x", moff, 0, 0) + _datatype(mt)
+        return struct.pack("<BHBI", 0x16, len(dt.names), 0, dt.itemsize) + body
     raise TypeError(f"h5file: unsupported dtype {dt}")
 
 

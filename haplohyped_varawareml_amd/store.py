@@ -144,7 +144,10 @@ class GenotypeStore:
         return rec
 
 
-def export_h5(store_path, h5_path):
+DONOR_CHUNK_ROWS = 7488          # 8 Blosc blocks of 936 records (32 760 B = the largest multiple of 35 under 32 KiB)
+
+
+def export_h5(store_path, h5_path, donor_records=False, ctx=None):
     """store directory -> one HDF5 file at the reference's output path (`OUT/{cohort}.h5`,
     /root/reference/src/haplohyped/vcf_to_h5.py:161), written natively (h5file.py; no h5py in this image):
 
@@ -158,7 +161,14 @@ def export_h5(store_path, h5_path):
     The reference's layout (S x 22 groups `donor_{id}/chr_{N}` of 35-byte compound records) is what
     GenotypeStore.snp_records / VCFH5Reader synthesise on demand; here every genotype is stored once.
     Needs Blosc-1 framed chunks (filter 32001 is hdf5-blosc / hdf5plugin.Blosc): stores written with
-    chunk_format="blosc1", which is what the converter does."""
+    chunk_format="blosc1", which is what the converter does.
+
+    donor_records=True adds the reference's literal layout for every donor of the sample list:
+        /donor_{id}/chr_{N}/snp_data   compound (35 B packed: chrom S5, start u4, stop u4, ref S10, alt S10, phase1 i1,
+                                       phase2 i1 — vcf_to_h5.py:119-135), chunks of 7488 records, filter 32001 with
+                                       typesize 35 (shuffle + LZ4 on the device, like every other chunk)
+    That is S x 22 datasets repeating the variant table per donor (263 GB raw for 2504 donors x 3 M variants), so the
+    converter only asks for it for small cohorts."""
     from .h5file import FILTER_BLOSC, H5Writer, blosc_cd_values
     meta = json.load(open(os.path.join(store_path, "meta.json")))
     if meta.get("chunk_format", "blosc2") != "blosc1":
@@ -198,4 +208,26 @@ def export_h5(store_path, h5_path):
             runs = json.load(open(os.path.join(d, "chrom_runs.json")))
             w.add_array(group, "chrom_run_first", np.array([r[0] for r in runs], np.uint32))
             w.add_array(group, "chrom_run_name", strings([r[1] for r in runs]) if runs else np.zeros(0, "S1"))
+        if donor_records:
+            import torch
+            from .device import BLOSC1
+            st = GenotypeStore(store_path, ctx=ctx)
+            c = st._context()
+            chunk_nbytes = DONOR_CHUNK_ROWS * SNP_DTYPE.itemsize
+            for donor in meta["donor_ids"]:
+                if donor not in st.samples:
+                    continue
+                for group in meta["groups"]:
+                    rec = st.snp_records(group, donor)
+                    n_chunks = -(-max(len(rec), 1) // DONOR_CHUNK_ROWS)
+                    padded = np.zeros(n_chunks * DONOR_CHUNK_ROWS, dtype=SNP_DTYPE)
+                    padded[:len(rec)] = rec
+                    src = torch.from_numpy(padded.view(np.uint8).reshape(-1)).to(c.device)
+                    dst, off, total = c.compress(src, chunk_nbytes, typesize=SNP_DTYPE.itemsize, blocksize=32760, fmt=BLOSC1)
+                    off = off.cpu().numpy()
+                    base = w.append(dst[:total].cpu().numpy().tobytes(), align=1)
+                    chunks = [((i * DONOR_CHUNK_ROWS,), base + int(off[i]), int(off[i + 1] - off[i])) for i in range(n_chunks)]
+                    w.add_chunked(f"donor_{donor}/{group}", "snp_data", (len(rec),), SNP_DTYPE, (DONOR_CHUNK_ROWS,), chunks,
+                                  filter_id=FILTER_BLOSC, cd_values=blosc_cd_values(SNP_DTYPE.itemsize, chunk_nbytes),
+                                  filter_name=b"blosc")
     return h5_path

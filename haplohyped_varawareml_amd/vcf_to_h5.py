@@ -23,13 +23,17 @@ logger = logging.getLogger("haplohyped.vcf_to_h5")
 
 class VCFtoHDF5Converter:
     def __init__(self, cohort_name: str, vcf_dir: str, out_dir: str, sample_list_path: str, cores: int,
-                 cxx_threads: int):
+                 cxx_threads: int, donor_records=None):
         self.cohort_name = cohort_name
         self.vcf_dir = vcf_dir
         self.out_dir = out_dir
         self.sample_list_path = sample_list_path
         self.cores = cores                # host inflate threads per file (BGZF)
         self.cxx_threads = cxx_threads    # kept for CLI compatibility (the reference's value is unused too)
+        # the reference's literal per-donor compound datasets in the .h5: None = only for cohorts of <= 32 donors;
+        # HHGT_DONOR_RECORDS=yes|no overrides (the CLI keeps exactly the reference's six options)
+        env = os.environ.get("HHGT_DONOR_RECORDS", "").lower()
+        self.donor_records = donor_records if donor_records is not None else {"yes": True, "no": False}.get(env)
         self.donor_ids = self.read_sample_list(sample_list_path)
         self.chromosomes = range(1, 23)
         self.tmp_dir = os.path.join(out_dir, "tmp_files")
@@ -108,7 +112,9 @@ class VCFtoHDF5Converter:
                             f"({fs.n_lines / max(fs.seconds, 1e-9):.0f} lines/s), ratio "
                             f"{fs.raw_bytes / max(fs.compressed_bytes, 1):.2f}")
             writer.close()
-            export_h5(self.store_path, self.h5_path)      # OUT/{cohort}.h5, readable by h5py + hdf5plugin
+            n_donors = len([d for d in self.donor_ids if d])
+            per_donor = self.donor_records if self.donor_records is not None else n_donors <= 32
+            export_h5(self.store_path, self.h5_path, donor_records=per_donor, ctx=ctx)   # OUT/{cohort}.h5 (h5py + hdf5plugin read it)
             logger.info(f"Total time taken: {time.time() - t0:.2f} seconds")
         finally:
             ctx.close()

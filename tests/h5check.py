@@ -27,7 +27,15 @@ with h5py.File(path, "r") as f:
                              for fl in filters])
         res[n + "|meta"] = np.array(json.dumps(meta))
         if not filters:
-            res[n] = d[...]
+            a = d[...]
+            if a.dtype.names:      # compound: one entry per member (structured npz entries do not survive numpy versions)
+                meta["fields"] = [[k, str(a.dtype.fields[k][0]), int(a.dtype.fields[k][1])] for k in a.dtype.names]
+                meta["itemsize"] = int(a.dtype.itemsize)
+                res[n + "|meta"] = np.array(json.dumps(meta))
+                for k in a.dtype.names:
+                    res[n + "|field|" + k] = np.ascontiguousarray(a[k])
+            else:
+                res[n] = a
         if n in dump:
             nchunks = d.id.get_num_chunks()
             meta["n_chunks"] = int(nchunks)

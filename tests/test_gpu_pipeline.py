@@ -114,3 +114,13 @@ def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
         ck4 = oracle.blosc_decompress(got["chr_4/genotype|chunk|0,0,0"]).view(np.int8).reshape(64, 8192, 2)
         assert np.array_equal(ck4[:3, :o4["n_kept"]], o4["G"])
         assert [x.decode() for x in got["chr_4/chrom_run_name"]] == ["chr4"] and list(got["chr_4/chrom_run_first"]) == [0]
+        # the reference's literal layout (3 donors: written by default): donor_{id}/chr_{N}/snp_data, 35-byte records
+        d0 = f"donor_{conv.donor_ids[1]}/chr_22/snp_data"
+        got = h5check(conv.h5_path, tmp_path, d0)
+        meta = json.loads(str(got[d0 + "|meta"]))
+        assert meta["shape"] == [1000] and meta["filters"][0][0] == 32001 and meta["filters"][0][2][2] == 35
+        recs = oracle.blosc_decompress(got[d0 + "|chunk|0"]).view(SNP_DTYPE)[:1000]
+        assert np.array_equal(recs["phase1"], G22[1, :, 0]) and np.array_equal(recs["phase2"], G22[1, :, 1])
+        assert recs["chrom"][0] == b"chr22" and int(recs["start"][0]) == 10012121 and int(recs["stop"][999]) == int(recs["start"][999]) + 1
+        if extlibs.have_blosc():
+            assert np.array_equal(extlibs.blosc1_decompress(got[d0 + "|chunk|0"], 7488 * 35).view(SNP_DTYPE)[:1000], recs)

@@ -118,3 +118,37 @@ def test_filter_32001_message_and_raw_chunks(tmp_path):
     for off, raw in payload.items():
         key = ",".join(str(o) for o in off)
         assert bytes(got["chr_1/genotype|chunk|" + key]) == raw and int(got["chr_1/genotype|mask|" + key]) == 0
+
+
+@needs_h5py
+def test_compound_records_like_the_reference(tmp_path):
+    """the reference's packed 35-byte record (vcf_to_h5.py:119-127) as a contiguous and as a chunked dataset"""
+    from haplohyped_varawareml_amd.store import SNP_DTYPE
+    rng = np.random.default_rng(5)
+    n = 1000
+    rec = np.zeros(n, dtype=SNP_DTYPE)
+    rec["chrom"] = b"chr22"
+    rec["start"] = np.sort(rng.integers(1, 1 << 28, n)).astype(np.uint32)
+    rec["stop"] = rec["start"] + 1
+    rec["ref"] = rng.choice([b"A", b"C", b"G", b"T"], n)
+    rec["alt"] = rng.choice([b"A", b"C", b"G", b"T"], n)
+    rec["phase1"] = rng.integers(-9, 2, n)
+    rec["phase2"] = rng.integers(0, 2, n)
+    p = str(tmp_path / "r.h5")
+    rows = 256
+    with h5file.H5Writer(p) as w:
+        w.add_array("donor_X/chr_22", "flat", rec)
+        chunks = []
+        for i in range(0, n, rows):
+            blk = np.zeros(rows, dtype=SNP_DTYPE)
+            blk[:len(rec[i:i + rows])] = rec[i:i + rows]
+            chunks.append(((i,), w.append(blk.tobytes(), align=1), blk.nbytes))
+        w.add_chunked("donor_X/chr_22", "snp_data", (n,), SNP_DTYPE, (rows,), chunks)
+    got = h5check(p, tmp_path)
+    for name in ("donor_X/chr_22/flat", "donor_X/chr_22/snp_data"):
+        meta = json.loads(str(got[name + "|meta"]))
+        assert meta["itemsize"] == 35 and meta["shape"] == [n]
+        assert [(k, off) for k, _, off in meta["fields"]] == [(k, SNP_DTYPE.fields[k][1]) for k in SNP_DTYPE.names]
+        assert [t for _, t, _ in meta["fields"]] == ["|S5", "uint32", "uint32", "|S10", "|S10", "int8", "int8"]
+        for k in SNP_DTYPE.names:
+            assert np.array_equal(got[name + "|field|" + k], rec[k]), (name, k)
