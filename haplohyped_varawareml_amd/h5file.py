@@ -61,9 +61,9 @@ def _dataspace(shape):
     return struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", int(d)) for d in shape)
 
 
-def _object_header(messages):
+def _object_header(messages, refcount=1):
     body = b"".join(messages)
-    return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body
+    return struct.pack("<BBHII4x", 1, 0, len(messages), refcount, len(body)) + body
 
 
 class H5Writer:
@@ -117,9 +117,11 @@ class H5Writer:
         ]
         self._link(group, name, self.append(_object_header(msgs)))
 
-    def add_chunked(self, group, name, shape, dtype, chunk_shape, chunks, filter_id=None, cd_values=(), filter_name=b""):
+    def add_chunked(self, group, name, shape, dtype, chunk_shape, chunks, filter_id=None, cd_values=(), filter_name=b"",
+                    aliases=()):
         """chunks: iterable of (offsets tuple in elements, file address, stored size in bytes[, filter mask]); every
-        chunk of the grid must be present (the converter always writes full grids)."""
+        chunk of the grid must be present (the converter always writes full grids).  aliases: further names in the
+        same group for the same object (hard links)."""
         dt = np.dtype(dtype)
         rank = len(shape)
         assert len(chunk_shape) == rank
@@ -141,7 +143,9 @@ class H5Writer:
         lay = struct.pack("<BBBQ", 3, 2, rank + 1, btree) + b"".join(struct.pack("<I", int(c)) for c in chunk_shape) + \
             struct.pack("<I", dt.itemsize)
         msgs.append(_msg(0x0008, lay))
-        self._link(group, name, self.append(_object_header(msgs)))
+        hdr = self.append(_object_header(msgs, refcount=1 + len(aliases)))
+        for nm in (name,) + tuple(aliases):
+            self._link(group, nm, hdr)
 
     def _chunk_btree(self, ents, rank, upper):
         """v1 B-tree, node type 1 (raw data chunks): key = (stored size u32, filter mask u32, offsets u64 x (rank+1))"""

@@ -164,7 +164,7 @@ def export_h5(store_path, h5_path, donor_records=False, ctx=None):
     chunk_format="blosc1", which is what the converter does.
 
     donor_records=True adds the reference's literal layout for every donor of the sample list:
-        /donor_{id}/chr_{N}/snp_data   compound (35 B packed: chrom S5, start u4, stop u4, ref S10, alt S10, phase1 i1,
+        /donor_{id}/chr_{N}/snp_data   (also linked as .../genotype, the name h5_reader.py:38-40 opens) compound (35 B packed: chrom S5, start u4, stop u4, ref S10, alt S10, phase1 i1,
                                        phase2 i1 — vcf_to_h5.py:119-135), chunks of 7488 records, filter 32001 with
                                        typesize 35 (shuffle + LZ4 on the device, like every other chunk)
     That is S x 22 datasets repeating the variant table per donor (263 GB raw for 2504 donors x 3 M variants), so the
@@ -229,5 +229,5 @@ def export_h5(store_path, h5_path, donor_records=False, ctx=None):
                     chunks = [((i * DONOR_CHUNK_ROWS,), base + int(off[i]), int(off[i + 1] - off[i])) for i in range(n_chunks)]
                     w.add_chunked(f"donor_{donor}/{group}", "snp_data", (len(rec),), SNP_DTYPE, (DONOR_CHUNK_ROWS,), chunks,
                                   filter_id=FILTER_BLOSC, cd_values=blosc_cd_values(SNP_DTYPE.itemsize, chunk_nbytes),
-                                  filter_name=b"blosc")
+                                  filter_name=b"blosc", aliases=("genotype",))   # the name the reference's reader opens (h5_reader.py:38-40)
     return h5_path

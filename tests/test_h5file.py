@@ -143,9 +143,9 @@ def test_compound_records_like_the_reference(tmp_path):
             blk = np.zeros(rows, dtype=SNP_DTYPE)
             blk[:len(rec[i:i + rows])] = rec[i:i + rows]
             chunks.append(((i,), w.append(blk.tobytes(), align=1), blk.nbytes))
-        w.add_chunked("donor_X/chr_22", "snp_data", (n,), SNP_DTYPE, (rows,), chunks)
+        w.add_chunked("donor_X/chr_22", "snp_data", (n,), SNP_DTYPE, (rows,), chunks, aliases=("genotype",))
     got = h5check(p, tmp_path)
-    for name in ("donor_X/chr_22/flat", "donor_X/chr_22/snp_data"):
+    for name in ("donor_X/chr_22/flat", "donor_X/chr_22/snp_data", "donor_X/chr_22/genotype"):
         meta = json.loads(str(got[name + "|meta"]))
         assert meta["itemsize"] == 35 and meta["shape"] == [n]
         assert [(k, off) for k, _, off in meta["fields"]] == [(k, SNP_DTYPE.fields[k][1]) for k in SNP_DTYPE.names]
