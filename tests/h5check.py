@@ -14,7 +14,15 @@ dump = set(sys.argv[3:])
 res = {}
 with h5py.File(path, "r") as f:
     names = []
-    f.visititems(lambda n, o: names.append((n, isinstance(o, h5py.Dataset))))
+
+    def walk(g, prefix):          # by link name (visititems reports a hard-linked object once)
+        for k in g.keys():
+            o = g[k]
+            names.append((prefix + k, isinstance(o, h5py.Dataset)))
+            if isinstance(o, h5py.Group):
+                walk(o, prefix + k + "/")
+
+    walk(f, "")
     res["|names"] = np.array(json.dumps(names))
     for n, is_ds in names:
         if not is_ds:
