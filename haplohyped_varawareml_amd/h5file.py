@@ -240,3 +240,182 @@ def blosc_cd_values(typesize, chunk_nbytes, clevel=5, shuffle=1, compcode=1):
     uncompressed chunk bytes, clevel, shuffle, compressor (1 = LZ4; the reference passes 2 = LZ4HC — same block
     format, and the header of each chunk says which decoder family it needs)]"""
     return (2, 2, int(typesize), int(chunk_nbytes), int(clevel), int(shuffle), int(compcode))
+
+
+class H5Reader:
+    """Reader for the same subset (files written by H5Writer, and h5py files that stay inside it: superblock v0/v1,
+    symbol-table groups, object headers v1 without continuation blocks in use, layout v3).  Gives dataset metadata,
+    contiguous arrays and the chunk index (address, stored size) — chunk payloads are decoded on the GPU by their
+    consumer, not here."""
+
+    def __init__(self, path):
+        self.path = path
+        self.f = open(path, "rb")
+        sb = self._at(0, 96)
+        if sb[:8] != SIG or sb[8] > 1 or sb[13] != 8 or sb[14] != 8:
+            raise ValueError(f"{path}: not an HDF5 file of the supported kind (superblock v0/v1, 8-byte offsets)")
+        root = 56 if sb[8] == 0 else 60                 # v1 carries 4 more bytes (indexed-storage K) before the addresses
+        self.root_header = struct.unpack_from("<Q", self._at(root, 40), 8)[0]
+        self._groups = {}
+
+    def close(self):
+        self.f.close()
+
+    def _at(self, addr, n):
+        self.f.seek(addr)
+        return self.f.read(n)
+
+    def _messages(self, addr):
+        ver, _, nmsgs, _, size = struct.unpack("<BBHII", self._at(addr, 12))
+        if ver != 1:
+            raise ValueError(f"{self.path}: object header version {ver} at {addr} is outside the supported subset")
+        blocks, out = [(addr + 16, size)], []
+        while blocks and len(out) < nmsgs:
+            a, n = blocks.pop(0)
+            body, p = self._at(a, n), 0
+            while p + 8 <= n and len(out) < nmsgs:
+                mtype, msize, _ = struct.unpack_from("<HHB", body, p)
+                data = body[p + 8:p + 8 + msize]
+                if mtype == 0x0010:                      # continuation block
+                    blocks.append(struct.unpack("<QQ", data[:16]))
+                out.append((mtype, data))
+                p += 8 + msize
+        return out
+
+    def _heap_string(self, heap_addr, off):
+        h = self._at(heap_addr, 32)
+        assert h[:4] == b"HEAP"
+        data_addr = struct.unpack_from("<Q", h, 24)[0]
+        s = self._at(data_addr + off, 256)
+        return s[:s.index(b"\0")].decode()
+
+    def group(self, header_addr=None):
+        """-> {name: object header address} of the group whose object header is at header_addr (default: root)"""
+        header_addr = self.root_header if header_addr is None else header_addr
+        if header_addr in self._groups:
+            return self._groups[header_addr]
+        st = [d for t, d in self._messages(header_addr) if t == 0x0011]
+        if not st:
+            raise KeyError("not a group")
+        bt, heap = struct.unpack("<QQ", st[0][:16])
+        out = {}
+
+        def walk(addr):
+            node = self._at(addr, 24)
+            assert node[:4] == b"TREE" and node[4] == 0
+            level, used = node[5], struct.unpack_from("<H", node, 6)[0]
+            body = self._at(addr + 24, 8 + used * 16)
+            for i in range(used):
+                child = struct.unpack_from("<Q", body, 8 + i * 16)[0]
+                if level:
+                    walk(child)
+                else:
+                    sn = self._at(child, 8)
+                    assert sn[:4] == b"SNOD"
+                    n = struct.unpack_from("<H", sn, 6)[0]
+                    ents = self._at(child + 8, n * 40)
+                    for k in range(n):
+                        noff, hdr = struct.unpack_from("<QQ", ents, k * 40)
+                        out[self._heap_string(heap, noff)] = hdr
+
+        walk(bt)
+        self._groups[header_addr] = out
+        return out
+
+    def resolve(self, path):
+        addr = self.root_header
+        for part in [p for p in path.split("/") if p]:
+            addr = self.group(addr)[part]
+        return addr
+
+    @staticmethod
+    def _dtype(b):
+        cls, ver = b[0] & 0x0F, b[0] >> 4
+        size = struct.unpack_from("<I", b, 4)[0]
+        if cls == 0:
+            return np.dtype(("i" if b[1] & 0x08 else "u") + str(size)), 12
+        if cls == 3:
+            return np.dtype(f"S{size}"), 8
+        if cls == 6 and ver == 1:
+            n = struct.unpack_from("<H", b, 1)[0]
+            p, names, fmts, offs = 8, [], [], []
+            for _ in range(n):
+                e = b.index(b"\0", p)
+                names.append(b[p:e].decode())
+                p += (e - p + 8) // 8 * 8
+                offs.append(struct.unpack_from("<I", b, p)[0])
+                p += 32
+                mt, used = H5Reader._dtype(b[p:])
+                fmts.append(mt)
+                p += used
+            return np.dtype(dict(names=names, formats=fmts, offsets=offs, itemsize=size)), p
+        raise ValueError(f"datatype class {cls} version {ver} is outside the supported subset")
+
+    def dataset(self, path):
+        """-> dict(shape, dtype, layout='contiguous'|'chunked', address/size or chunk_shape + chunks {offsets: (addr, size, mask)},
+        filters [(id, cd_values)])"""
+        info = dict(filters=[])
+        for t, d in self._messages(self.resolve(path)):
+            if t == 0x0001:
+                rank = d[1]
+                info["shape"] = tuple(struct.unpack_from(f"<{rank}Q", d, 8)) if rank else ()
+            elif t == 0x0003:
+                info["dtype"] = self._dtype(d)[0]
+            elif t == 0x000B:
+                p = 8
+                for _ in range(d[1]):
+                    fid, nlen, _, ncd = struct.unpack_from("<HHHH", d, p)
+                    p += 8 + nlen
+                    info["filters"].append((fid, tuple(struct.unpack_from(f"<{ncd}I", d, p))))
+                    p += 4 * (ncd + ncd % 2)
+            elif t == 0x0008:
+                if d[0] != 3:
+                    raise ValueError("data layout version outside the supported subset")
+                if d[1] == 1:
+                    info.update(layout="contiguous", address=struct.unpack_from("<Q", d, 2)[0], size=struct.unpack_from("<Q", d, 10)[0])
+                elif d[1] == 2:
+                    nd = d[2]
+                    dims = struct.unpack_from(f"<{nd}I", d, 11)
+                    info.update(layout="chunked", btree=struct.unpack_from("<Q", d, 3)[0], chunk_shape=tuple(dims[:-1]))
+                else:
+                    raise ValueError("compact layout is outside the supported subset")
+        if info.get("layout") == "chunked":
+            info["chunks"] = self._chunk_index(info["btree"], len(info["chunk_shape"]))
+        return info
+
+    def _chunk_index(self, addr, rank):
+        out = {}
+        if addr == UNDEF:
+            return out
+        keysize = 8 + 8 * (rank + 1)
+
+        def walk(a):
+            node = self._at(a, 24)
+            assert node[:4] == b"TREE" and node[4] == 1
+            level, used = node[5], struct.unpack_from("<H", node, 6)[0]
+            body = self._at(a + 24, used * (keysize + 8))
+            for i in range(used):
+                p = i * (keysize + 8)
+                size, mask = struct.unpack_from("<II", body, p)
+                offs = struct.unpack_from(f"<{rank}Q", body, p + 8)
+                child = struct.unpack_from("<Q", body, p + keysize)[0]
+                if level:
+                    walk(child)
+                else:
+                    out[tuple(int(o) for o in offs)] = (child, size, mask)
+
+        walk(addr)
+        return out
+
+    def read_array(self, path):
+        info = self.dataset(path)
+        if info["layout"] != "contiguous":
+            raise ValueError(f"{path}: chunked datasets are read chunk by chunk (read_chunk)")
+        n = int(np.prod(info["shape"])) if info["shape"] else 1
+        if info["size"] == 0 or n == 0:
+            return np.zeros(info["shape"], info["dtype"])
+        return np.frombuffer(self._at(info["address"], info["size"]), dtype=info["dtype"]).reshape(info["shape"]).copy()
+
+    def read_chunk(self, info, offsets):
+        addr, size, _ = info["chunks"][tuple(offsets)]
+        return np.frombuffer(self._at(addr, size), dtype=np.uint8)

@@ -78,15 +78,54 @@ class StoreWriter:
 
 
 class GenotypeStore:
-    """Reader.  Decoding runs on the GPU (hhgt_decompress_chunks); there is no CPU decode path in the
-    product."""
+    """Reader.  Opens either the working store directory or the HDF5 file the converter exports
+    (`OUT/{cohort}.h5`: read natively through h5file.H5Reader — metadata and raw chunks only).  Decoding runs on the
+    GPU (hhgt_decompress_chunks); there is no CPU decode path in the product."""
 
     def __init__(self, path, ctx=None):
         self.path = path
-        self.meta = json.load(open(os.path.join(path, "meta.json")))
-        self.samples = self.meta["samples"]
         self._ctx = ctx
+        self._h5 = None
+        if os.path.isdir(path):
+            self.meta = json.load(open(os.path.join(path, "meta.json")))
+        else:
+            self._open_h5(path)
+        self.samples = self.meta["samples"]
         self._idx = {s: i for i, s in enumerate(self.samples)}
+
+    def _open_h5(self, path):
+        from .h5file import FILTER_BLOSC, H5Reader
+        r = H5Reader(path)
+        root = r.group()
+        if "samples" not in root:
+            raise ValueError(f"{path}: no /samples dataset — not a cohort file written by vcf_to_h5")
+        samples = [x.decode() for x in r.read_array("samples")]
+        donors = [x.decode() for x in r.read_array("donor_ids")] if "donor_ids" in root else list(samples)
+        meta = dict(format="hhgt-h5", samples=samples, donor_ids=donors, groups={}, chunk_format="blosc1")
+        self._h5_info = {}
+        for name in sorted(root):
+            try:
+                members = r.group(root[name])
+            except KeyError:
+                continue
+            if not name.startswith("chr_") or "genotype" not in members:
+                continue
+            info = r.dataset(f"{name}/genotype")
+            if not info["filters"] or info["filters"][0][0] != FILTER_BLOSC:
+                raise ValueError(f"{path}:{name}/genotype is not a filter-32001 dataset")
+            sc, vc = int(info["chunk_shape"][0]), int(info["chunk_shape"][1])
+            first = r.read_chunk(info, (0, 0, 0))
+            meta.update(sc=sc, vc=vc, typesize=int(first[3]), blocksize=int(first[8:12].view("<u4")[0]))
+            meta["groups"][name] = dict(n_variants=int(info["shape"][1]), n_vcol=-(-max(int(info["shape"][1]), 1) // vc),
+                                        n_scol=-(-max(len(samples), 1) // sc), n_chunks=len(info["chunks"]))
+            self._h5_info[name] = info
+        self.meta = meta
+        self._h5 = r
+
+    def close(self):
+        if self._h5 is not None:
+            self._h5.close()
+            self._h5 = None
 
     def _context(self):
         if self._ctx is None:
@@ -98,9 +137,27 @@ class GenotypeStore:
         return list(self.meta["groups"])
 
     def variants(self, group):
+        if self._h5 is not None:
+            r = self._h5
+            runs = list(zip((int(x) for x in r.read_array(f"{group}/chrom_run_first")),
+                            (x.decode() for x in r.read_array(f"{group}/chrom_run_name"))))
+            return (r.read_array(f"{group}/start"), r.read_array(f"{group}/ref").view(np.uint8),
+                    r.read_array(f"{group}/alt").view(np.uint8), [list(x) for x in runs])
         d = os.path.join(self.path, group)
         return (np.load(os.path.join(d, "start.npy")), np.load(os.path.join(d, "ref.npy")),
                 np.load(os.path.join(d, "alt.npy")), json.load(open(os.path.join(d, "chrom_runs.json"))))
+
+    def _chunk_row(self, group, scol):
+        """framed chunks (vcol = 0 .. n_vcol-1) of sample-chunk row `scol`, as a list of uint8 arrays"""
+        g = self.meta["groups"][group]
+        sc, vc = self.meta["sc"], self.meta["vc"]
+        if self._h5 is not None:
+            info = self._h5_info[group]
+            return [self._h5.read_chunk(info, (scol * sc, v * vc, 0)) for v in range(g["n_vcol"])]
+        off = np.load(os.path.join(self.path, group, "offsets.npy"))
+        mm = np.memmap(os.path.join(self.path, group, "chunks.bin"), dtype=np.uint8, mode="r")
+        ids = [v * g["n_scol"] + scol for v in range(g["n_vcol"])]
+        return [np.asarray(mm[int(off[i]):int(off[i + 1])]) for i in ids]
 
     def sample_row(self, group, sample):
         """int8 [n_variants, 2] for one sample: decodes the sample's chunk row on the GPU."""
@@ -109,22 +166,19 @@ class GenotypeStore:
         s = self._idx[sample] if isinstance(sample, str) else int(sample)
         sc, vc = self.meta["sc"], self.meta["vc"]
         scol, sin = divmod(s, sc)
-        off = np.load(os.path.join(self.path, group, "offsets.npy"))
-        mm = np.memmap(os.path.join(self.path, group, "chunks.bin"), dtype=np.uint8, mode="r")
-        ids = [v * g["n_scol"] + scol for v in range(g["n_vcol"])]
-        parts, rel = [], [0]
-        for i in ids:
-            parts.append(np.asarray(mm[int(off[i]):int(off[i + 1])]))
-            rel.append(rel[-1] + parts[-1].size)
+        parts = self._chunk_row(group, scol)
+        rel = [0]
+        for part in parts:
+            rel.append(rel[-1] + part.size)
         ctx = self._context()
         src = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.uint8)).to(ctx.device)
         d_off = torch.tensor(rel, dtype=torch.int64, device=ctx.device)
         chunk_nbytes = sc * vc * 2
-        out, bad = ctx.decompress(src, d_off, len(ids), chunk_nbytes, typesize=self.meta["typesize"],
+        out, bad = ctx.decompress(src, d_off, len(parts), chunk_nbytes, typesize=self.meta["typesize"],
                                   blocksize=self.meta["blocksize"])
         if bad:
             raise RuntimeError(f"{bad} corrupt chunk(s) in {group}")
-        rows = out.view(torch.int8).view(len(ids), sc, vc, 2)[:, sin].reshape(-1, 2)
+        rows = out.view(torch.int8).view(len(parts), sc, vc, 2)[:, sin].reshape(-1, 2)
         return rows[: g["n_variants"]].cpu().numpy()
 
     def snp_records(self, group, sample):

@@ -88,6 +88,13 @@ def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
         assert np.array_equal(r4["start"], o4["start"]) and b"".join(r4["ref"].tolist()) == bytes(o4["ref"])
     with pytest.raises(KeyError):
         rd.fetch_genotypes(conv.donor_ids[0], 5)
+    # the exported HDF5 file alone serves the same records (read natively: h5file.H5Reader + GPU decode)
+    rd5 = VCFH5Reader(conv.h5_path, ctx=ctx)
+    assert sorted(rd5.store.groups()) == ["chr_22", "chr_4"] and rd5.store.samples == names
+    for donor in conv.donor_ids:
+        for chrom in (22, 4):
+            a, b = rd.fetch_genotypes(donor, chrom), rd5.fetch_genotypes(donor, chrom)
+            assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
     # every stored chunk is a Blosc-1 frame (filter 32001) the oracle decodes to the chunk-tiled matrix bytes
     off = np.load(os.path.join(store, "chr_22", "offsets.npy"))
     raw = np.fromfile(os.path.join(store, "chr_22", "chunks.bin"), dtype=np.uint8)

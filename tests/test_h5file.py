@@ -152,3 +152,66 @@ def test_compound_records_like_the_reference(tmp_path):
         assert [t for _, t, _ in meta["fields"]] == ["|S5", "uint32", "uint32", "|S10", "|S10", "int8", "int8"]
         for k in SNP_DTYPE.names:
             assert np.array_equal(got[name + "|field|" + k], rec[k]), (name, k)
+
+
+def test_reader_roundtrip_own_files(tmp_path):
+    """H5Reader over H5Writer output (no external library): names, arrays, compound dtype, chunk index, filters"""
+    from haplohyped_varawareml_amd.store import SNP_DTYPE
+    p = str(tmp_path / "rt.h5")
+    rng = np.random.default_rng(9)
+    rec = np.zeros(10, dtype=SNP_DTYPE)
+    rec["start"] = np.arange(10)
+    payload = {}
+    with h5file.H5Writer(p) as w:
+        w.add_array("/", "samples", np.array([b"a", b"bb"], dtype="S2"))
+        w.add_array("g/h", "rec", rec)
+        for i in range(40):
+            w.add_array("many", f"d{i}", np.full(3, i, np.uint32))
+        chunks = []
+        for vi in range(0, 300 * 8, 8):
+            raw = rng.integers(0, 256, 11 + vi % 7, dtype=np.uint8).tobytes()
+            payload[(0, vi, 0)] = raw
+            chunks.append(((0, vi, 0), w.append(raw, align=1), len(raw)))
+        w.add_chunked("chr_9", "genotype", (60, 300 * 8 - 3, 2), np.int8, (64, 8, 2), chunks, filter_id=32001,
+                      cd_values=h5file.blosc_cd_values(2, 64 * 8 * 2), filter_name=b"blosc", aliases=("alias",))
+    r = h5file.H5Reader(p)
+    assert sorted(r.group()) == ["chr_9", "g", "many", "samples"] and len(r.group(r.resolve("many"))) == 40
+    assert list(r.read_array("samples")) == [b"a", b"bb"] and np.array_equal(r.read_array("many/d39"), np.full(3, 39, np.uint32))
+    got = r.read_array("g/h/rec")
+    assert got.dtype == SNP_DTYPE and np.array_equal(got["start"], rec["start"])
+    d = r.dataset("chr_9/alias")
+    assert d["shape"] == (60, 300 * 8 - 3, 2) and d["dtype"] == np.int8 and d["chunk_shape"] == (64, 8, 2)
+    assert d["filters"] == [(32001, (2, 2, 2, 64 * 8 * 2, 5, 1, 1))] and len(d["chunks"]) == 300
+    for off, raw in payload.items():
+        assert bytes(r.read_chunk(d, off)) == raw
+    r.close()
+
+
+@needs_h5py
+def test_reader_on_a_file_written_by_libhdf5(tmp_path):
+    """the other direction: a file produced by h5py/libhdf5 (default, oldest-compatible format) read by H5Reader"""
+    p = str(tmp_path / "lib.h5")
+    script = (
+        "import h5py, numpy as np\n"
+        f"f = h5py.File({p!r}, 'w')\n"
+        "f['samples'] = np.array([b'NA1', b'NA22'], dtype='S4')\n"
+        "g = f.create_group('chr_1')\n"
+        "g['start'] = np.arange(1000, dtype=np.uint32) * 3\n"
+        "d = g.create_dataset('genotype', shape=(70, 500, 2), dtype='i1', chunks=(64, 100, 2))\n"
+        "G = (np.arange(70 * 500 * 2) % 5 - 2).astype('i1').reshape(70, 500, 2)\n"
+        "d[...] = G\n"
+        "for i in range(30): f.create_group('many').create_dataset('x%d' % i, data=np.full(2, i, 'u2')) if i == 0 else f['many'].create_dataset('x%d' % i, data=np.full(2, i, 'u2'))\n"
+        "f.close()\n")
+    r = subprocess.run([CONDA_PY, "-c", script], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rd = h5file.H5Reader(p)
+    assert sorted(rd.group()) == ["chr_1", "many", "samples"]
+    assert list(rd.read_array("samples")) == [b"NA1", b"NA22"]
+    assert np.array_equal(rd.read_array("chr_1/start"), np.arange(1000, dtype=np.uint32) * 3)
+    assert np.array_equal(rd.read_array("many/x29"), np.full(2, 29, np.uint16))
+    d = rd.dataset("chr_1/genotype")
+    assert d["shape"] == (70, 500, 2) and d["chunk_shape"] == (64, 100, 2) and len(d["chunks"]) == 10 and d["filters"] == []
+    G = (np.arange(70 * 500 * 2) % 5 - 2).astype("i1").reshape(70, 500, 2)
+    blk = rd.read_chunk(d, (64, 400, 0)).view(np.int8).reshape(64, 100, 2)
+    assert np.array_equal(blk[:6], G[64:70, 400:500])
+    rd.close()
