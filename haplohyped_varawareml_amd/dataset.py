@@ -87,12 +87,11 @@ class ReferenceGenome:
     def __init__(self, path, encode_spec=None, device=None, ctx=None):
         self.encode_spec = parse_encode_dict(encode_spec)
         self._store = None
-        if os.path.isdir(str(path)):
-            # the one-hot reference store written by fasta_encoder (fasta_encoder.py's reference_genome.h5)
+        if os.path.isdir(str(path)) or str(path).endswith((".h5", ".hdf5")):
+            # the one-hot reference written by fasta_encoder: its store directory, or OUT/reference_genome.h5
             from .fasta_encoder import ReferenceGenome as EncodedGenome
             self._store = EncodedGenome(hdf5_file=str(path), ctx=ctx)
-            meta = json.load(open(os.path.join(str(path), "meta.json")))
-            self.contigs = {c: None for c in meta["contigs"]}
+            self.contigs = {c: None for c in self._store.contigs()}
         elif str(path).endswith(".npz"):
             z = np.load(path)
             self.contigs = {k: z[k] for k in z.files}

@@ -134,27 +134,59 @@ class ReferenceGenome:
         """int8 [end-start, C] one-hot rows (fasta_encoder.py:111-118), decoded on the device"""
         return self.get_sequence_device(chrom, start, end).cpu().numpy()
 
+    def _h5(self):
+        """`hdf5_file` may be the store directory or the single file HDF5Handler.save_to_hdf5 wrote
+        (OUT/reference_genome.h5, what the reference's ReferenceGenome(hdf5_file=...) is given)"""
+        if self.hdf5_file and os.path.isfile(self.hdf5_file):
+            if getattr(self, "_h5r", None) is None:
+                from .h5file import H5Reader
+                self._h5r = H5Reader(self.hdf5_file)
+                self._h5d = {}
+            return self._h5r
+        return None
+
+    def contigs(self):
+        r = self._h5()
+        if r is not None:
+            return sorted(r.group())
+        return sorted(json.load(open(os.path.join(self.hdf5_file or self.output_dir, "meta.json")))["contigs"])
+
     def contig_meta(self, chrom):
+        r = self._h5()
+        if r is not None:
+            if chrom not in self._h5d:
+                info = r.dataset(f"{chrom}/sequence")
+                first = r.read_chunk(info, (0, 0))
+                self._h5d[chrom] = dict(info=info, length=int(info["shape"][0]), chunk_rows=int(info["chunk_shape"][0]),
+                                        columns=[c.decode() for c in r.read_array(f"{chrom}/columns")], typesize=1,
+                                        blocksize=int(first[8:12].view("<u4")[0]))
+            return self._h5d[chrom]
         gdir = self.genome_df[chrom] if self.genome_df else os.path.join(self.hdf5_file or self.output_dir, chrom)
         return json.load(open(os.path.join(gdir, "meta.json")))
 
     def get_sequence_device(self, chrom, start, end):
         import torch
-        gdir = self.genome_df[chrom] if self.genome_df else os.path.join(self.hdf5_file or self.output_dir, chrom)
-        meta = json.load(open(os.path.join(gdir, "meta.json")))
+        meta = self.contig_meta(chrom)
         nch, rows = len(meta["columns"]), meta["chunk_rows"]
         start, end = max(0, int(start)), min(int(end), meta["length"])
         if end <= start:
             return torch.zeros((0, nch), dtype=torch.int8, device=self._context().device)
         c0, c1 = start // rows, (end - 1) // rows + 1
-        off = np.load(os.path.join(gdir, "offsets.npy"))
-        mm = np.memmap(os.path.join(gdir, "chunks.bin"), dtype=np.uint8, mode="r")
         ctx = self._context()
-        src = torch.from_numpy(np.array(mm[int(off[c0]):int(off[c1])])).to(ctx.device)
-        d_off = torch.from_numpy((off[c0:c1 + 1] - off[c0]).astype(np.int64)).to(ctx.device)
+        if self._h5() is not None:
+            parts = [self._h5r.read_chunk(meta["info"], (i * rows, 0)) for i in range(c0, c1)]
+            off = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.uint64)
+            src = torch.from_numpy(np.concatenate(parts)).to(ctx.device)
+            d_off = torch.from_numpy(off.astype(np.int64)).to(ctx.device)
+        else:
+            gdir = self.genome_df[chrom] if self.genome_df else os.path.join(self.hdf5_file or self.output_dir, chrom)
+            off = np.load(os.path.join(gdir, "offsets.npy"))
+            mm = np.memmap(os.path.join(gdir, "chunks.bin"), dtype=np.uint8, mode="r")
+            src = torch.from_numpy(np.array(mm[int(off[c0]):int(off[c1])])).to(ctx.device)
+            d_off = torch.from_numpy((off[c0:c1 + 1] - off[c0]).astype(np.int64)).to(ctx.device)
         out, bad = ctx.decompress(src, d_off, c1 - c0, rows * nch, typesize=1, blocksize=meta["blocksize"])
         if bad:
-            raise RuntimeError(f"{bad} corrupt chunk(s) in {gdir}")
+            raise RuntimeError(f"{bad} corrupt chunk(s) of {chrom} in {self.hdf5_file or self.output_dir}")
         return out.view(torch.int8).view(-1, nch)[start - c0 * rows: end - c0 * rows]
 
 

@@ -150,7 +150,8 @@ def test_dataset_reads_fasta_encoder_store(ctx, tmp_path, golden_dir):
     assert np.array_equal(ds.reference_genome.host_bases("chr22"), up)
     ds.close()
     # the same dataset over the exported HDF5 file (the reference's `hdf5_genotype_file` argument) instead of the store
-    ds5 = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), str(tmp_path / "out" / "c.h5"), ref_store, samples,
+    ds5 = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), str(tmp_path / "out" / "c.h5"),
+                                 str(tmp_path / "out" / "reference_genome.h5"), samples,
                                  seed=1, batch_size=4, seq_length=2000, ctx=ctx)
     g1, g2 = ds5[0]
     assert torch.equal(g1, h1) and torch.equal(g2, h2)
