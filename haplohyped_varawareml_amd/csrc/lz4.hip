@@ -26,6 +26,16 @@
 #define LZ_MINMATCH 4u
 #define LZ_MFLIMIT 12u
 #define LZ_LASTLITERALS 5u
+// Shortest offset-1 run / hash match the window encoder takes as a sequence.  LZ4 allows 4; on the genotype workload
+// a 4-5 byte match saves 1-2 bytes but ends the literal run and often pre-empts a better match one position later
+// (the parse is greedy): measured ratio 4.326 with 4/4, 4.399 with 5/5, **4.410 with 6/6**, 4.352 with 7/7,
+// 4.231 with 8/8 — and fewer sequences are less work (35.4 -> 35.0 ms).  Override with -DLZ_MINRUN= / -DLZ_MINHASH=.
+#ifndef LZ_MINRUN
+#define LZ_MINRUN 6u
+#endif
+#ifndef LZ_MINHASH
+#define LZ_MINHASH 6u
+#endif
 
 size_t lz4_slot_bytes(int neblock)
 {
@@ -351,7 +361,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             const uint32_t f = f_lo < f_hi ? f_lo : f_hi;
             const uint32_t run = f < to_end ? f : to_end;
             // per-lane predicates are wave masks (SGPR pairs written by v_cmp), combined on the scalar unit
-            const unsigned long long Rm = ballot(run >= 4u);
+            const unsigned long long Rm = ballot(run >= LZ_MINRUN);
             unsigned long long Hm = 0ull;
             if constexpr (!FAST) Hm = ballot(d == __builtin_amdgcn_alignbyte(cw.w[1], cw.w[0], hsh));
             // the table starts zeroed, so hcand < pos except at position 0; candidates need no range test:
@@ -393,8 +403,8 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lenr, 0x130, 0xf, 0xf, true);  // wave_shl:1, 0 shifted in
                 const uint32_t r2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r1, 0x130, 0xf, 0xf, true);
                 const unsigned long long DOMm = (ballot(r1 + 1u > lenh) & (Rm >> 1)) | (ballot(r2 + 2u > lenh) & (Rm >> 2));  // Rm >> k: lane + k starts a run
-                const unsigned long long drop = Hm & DOMm & ~Rm;  // lanes with a run of their own stay candidates
-                Hm &= ~DOMm;
+                const unsigned long long drop = Hm & (DOMm | ballot(lenh < LZ_MINHASH)) & ~Rm;  // lanes with a run of their own stay candidates
+                Hm &= ~(DOMm | ballot(lenh < LZ_MINHASH));
                 M &= ~drop;
                 lenh = __builtin_amdgcn_inverse_ballot_w64(Hm) ? lenh : 0u;
                 if (M == 0ull) {
