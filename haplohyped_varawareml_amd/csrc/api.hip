@@ -518,7 +518,7 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
         TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize,
-                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel <= 2 ? 1 : 0, st));
+                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel <= 2 ? 1 : (c->clevel >= 7 ? 2 : 0), st));
         t.stop();
     }
     {

@@ -315,7 +315,7 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
 // room.  So per-lane predicates live as wave masks in SGPR pairs (v_cmp writes them for free), everything
 // wave-uniform (range limits, the position-0 exclusion, end-of-stream clipping) is scalar and branched
 // around, and the enqueue runs under exec = SEL set by two scalar moves instead of a per-lane test.
-template <bool FAST>
+template <bool FAST, bool LONGRUN>
 __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint32_t n, uint16_t *tab,
                                                          uint32_t hashlog, uint8_t *__restrict__ out, uint2 *queue)
 {
@@ -332,6 +332,7 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
         Own6 own = lds_load6(in, lane);
         // byte before this lane's position (0x100 = "none": position 0 continues no run)
         uint32_t pbv = lane ? (uint32_t)in[lane - 1u] : 0x100u;
+        uint32_t best_start = 0u, best_len = 0u, best_byte = 0x100u;  // longest extended run so far (none yet)
         LZ_STAT(0, 1);
         while (p <= mflimit) {
             LZ_STAT(1, 1);
@@ -366,11 +367,12 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             if constexpr (!FAST) Hm = ballot(d == __builtin_amdgcn_alignbyte(cw.w[1], cw.w[0], hsh));
             // the table starts zeroed, so hcand < pos except at position 0; candidates need no range test:
             // position 0 and lanes past mflimit are taken out of M on the scalar side, in the two windows that have them
-            unsigned long long M = Hm | Rm;
+            unsigned long long M = Hm | Rm, range_m = ~0ull;
             if (p - 1u >= lim63) {
                 asm volatile("" ::: "memory");  // keep this a (rarely taken) scalar branch
-                if (p == 0u) M &= ~1ull;
-                if (p + 63u > mflimit) M &= ~0ull >> (63u - (mflimit - p));
+                if (p == 0u) range_m &= ~1ull;
+                if (p + 63u > mflimit) range_m &= ~0ull >> (63u - (mflimit - p));
+                M &= range_m;
             }
             if (M == 0ull) {
                 LZ_STAT(2, 1);
@@ -402,6 +404,26 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 // (a second compare batch for bytes 20..35 ran in 80 % of the windows, tools/lz4_stats.py).
                 const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lenr, 0x130, 0xf, 0xf, true);  // wave_shl:1, 0 shifted in
                 const uint32_t r2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r1, 0x130, 0xf, 0xf, true);
+                // Third candidate: the first byte of a run (it differs from its predecessor, so offset 1 cannot cover
+                // it) copied together with the run from the LONGEST EARLIER RUN of the same byte value.  The hash
+                // table's most recent "0000" sits at the end of the previous run, four bytes before the '1' that ends
+                // it — a source that dies after 4 bytes; LZ4HC's chain search finds the long one, which is why c-blosc's
+                // lz4hc (what the reference's compression_opts select) packs these planes far tighter than lz4.  The
+                // wave remembers the longest extended run so far (start, length, byte value; scalar registers).
+                // Costs 15 % kernel time for 4 % ratio on the bench workload: the higher-effort mode (clevel >= 7).
+                const unsigned long long Lm0 = LONGRUN ? ballot((d & 0xFFu) == best_byte) & ~E & (Rm >> 1) & range_m : 0ull;
+                if (LONGRUN && Lm0 != 0ull) {
+                    const uint32_t want = r1 + 1u;                                    // this byte + the run behind it
+                    const uint32_t lenl = want < best_len ? want : best_len;
+                    const unsigned long long Lm = Lm0 & ballot(lenl > lenh);
+                    const bool isl = __builtin_amdgcn_inverse_ballot_w64(Lm);
+                    lenh = isl ? lenl : lenh;
+                    hcand = isl ? best_start : hcand;
+                    Hm |= Lm;
+                    M |= Lm;
+                    // still matching: the run reaches the window end and the source run is longer than that
+                    Zm = (Zm & ~Lm) | (Lm & ballot(want == to_end) & ballot(best_len > want));
+                }
                 const unsigned long long DOMm = (ballot(r1 + 1u > lenh) & (Rm >> 1)) | (ballot(r2 + 2u > lenh) & (Rm >> 2));  // Rm >> k: lane + k starts a run
                 const unsigned long long drop = Hm & (DOMm | ballot(lenh < LZ_MINHASH)) & ~Rm;  // lanes with a run of their own stay candidates
                 Hm &= ~(DOMm | ballot(lenh < LZ_MINHASH));
@@ -486,6 +508,11 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 }
                 len = lane == last ? ml : len;
                 lcur = last + ml;
+                if (LONGRUN && ((RFm >> last) & 1ull) && ml + 1u > best_len) {  // a longer run of one byte value: bytes ps-1 .. ps+ml-1
+                    best_len = ml + 1u;
+                    best_start = ps - 1u;
+                    best_byte = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)last) & 0xFFu;
+                }
             }
             // next window's own bytes: request now, consumed after the enqueue below
             const uint32_t np = p + (lcur > 64u ? lcur : 64u);
@@ -607,8 +634,9 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
         const uint32_t qoff = (nwaves * sstride + 16u + nwaves * ((2u << hashlog) + 4u) + 7u) & ~7u;
         uint2 *queue = reinterpret_cast<uint2 *>(smem + qoff) + wave * 64u;
         uint32_t cs = ALGO == 1   ? lz4_wave_compress(in, neblock, tb, hashlog, out)
-                      : ALGO == 5 ? lz4_wave_compress_v6<true>(in, neblock, tb, hashlog, out, queue)
-                                  : lz4_wave_compress_v6<false>(in, neblock, tb, hashlog, out, queue);
+                      : ALGO == 5 ? lz4_wave_compress_v6<true, false>(in, neblock, tb, hashlog, out, queue)
+                      : ALGO == 7 ? lz4_wave_compress_v6<false, true>(in, neblock, tb, hashlog, out, queue)
+                                  : lz4_wave_compress_v6<false, false>(in, neblock, tb, hashlog, out, queue);
         (void)algo;
         if (cs >= neblock) {  // incompressible: Blosc stores the (shuffled) stream verbatim
             for (uint32_t k = lane; k < neblock; k += 64u) out[k] = in[k];
@@ -664,8 +692,8 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     if (lds > attr_lds) {
         const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1>), reinterpret_cast<const void *>(k_lz4_blocks<0, 5>),
                              reinterpret_cast<const void *>(k_lz4_blocks<8, 5>), reinterpret_cast<const void *>(k_lz4_blocks<0, 6>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<6, 6>), reinterpret_cast<const void *>(k_lz4_blocks<7, 6>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<8, 6>)};
+                             reinterpret_cast<const void *>(k_lz4_blocks<7, 6>), reinterpret_cast<const void *>(k_lz4_blocks<8, 6>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<0, 7>), reinterpret_cast<const void *>(k_lz4_blocks<7, 7>)};
         for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
@@ -691,12 +719,15 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
                        (uint64_t)slot_bytes, d_csize)
+    // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
+    // long-run source candidate (clevel 7-9)
     if (algo == 1u) LZ_LAUNCH(0, 1);
-    else if (fast && nwaves <= 2) LZ_LAUNCH(8, 5);
-    else if (fast) LZ_LAUNCH(0, 5);
+    else if (fast == 1 && nwaves <= 2) LZ_LAUNCH(8, 5);
+    else if (fast == 1) LZ_LAUNCH(0, 5);
+    else if (fast == 2 && nwaves <= 2) LZ_LAUNCH(7, 7);
+    else if (fast == 2) LZ_LAUNCH(0, 7);
     else if (mw == 8) LZ_LAUNCH(8, 6);
     else if (mw == 7) LZ_LAUNCH(7, 6);
-    else if (mw == 6) LZ_LAUNCH(6, 6);
     else LZ_LAUNCH(0, 6);
 #undef LZ_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -133,13 +133,19 @@ def test_many_short_sequences_fill_the_queue(ctx):
     compress_streams(ctx, np.concatenate([a, b]), n)
 
 
-def test_fast_mode_same_patterns(ctx):
-    """clevel 1 (run candidate only) over the sparse and the boundary patterns"""
+@pytest.mark.parametrize("clevel", [1, 9])
+def test_other_effort_levels_same_patterns(ctx, clevel):
+    """clevel 1 (run candidate only) and clevel 9 (plus the long-run source candidate) over the sparse and the
+    boundary patterns; the higher effort must not compress worse than the default on sparse planes"""
+    n = 4096
+    rng = np.random.default_rng(5)
+    data = np.concatenate([sparse(rng, n, p, missing=0.003) for p in (0.001, 0.01, 0.03, 0.1, 0.5)] * 4 + [np.zeros(n, np.uint8)] +
+                          [np.where(np.arange(n) % g == 0, 1, 0).astype(np.uint8) for g in (7, 19, 33, 70, 200)])
+    base = sum(s.size if s is not None else n for s, _ in compress_streams(ctx, data, n))
     try:
-        ctx.set_clevel(1)
-        n = 4096
-        rng = np.random.default_rng(5)
-        data = np.concatenate([sparse(rng, n, p) for p in (0.001, 0.01, 0.1, 0.5)] + [np.zeros(n, np.uint8)])
-        compress_streams(ctx, data, n)
+        ctx.set_clevel(clevel)
+        got = sum(s.size if s is not None else n for s, _ in compress_streams(ctx, data, n))
     finally:
         ctx.set_clevel(5)
+    if clevel == 9:
+        assert got <= base, (got, base)
