@@ -30,6 +30,9 @@
 // a 4-5 byte match saves 1-2 bytes but ends the literal run and often pre-empts a better match one position later
 // (the parse is greedy): measured ratio 4.326 with 4/4, 4.399 with 5/5, **4.410 with 6/6**, 4.352 with 7/7,
 // 4.231 with 8/8 — and fewer sequences are less work (35.4 -> 35.0 ms).  Override with -DLZ_MINRUN= / -DLZ_MINHASH=.
+#ifndef LZ_BACK_STEPS
+#define LZ_BACK_STEPS 1   // backward-extension rounds of the high-effort mode
+#endif
 #ifndef LZ_MINRUN
 #define LZ_MINRUN 6u
 #endif
@@ -333,7 +336,6 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
         // byte before this lane's position (0x100 = "none": position 0 continues no run)
         uint32_t pbv = lane ? (uint32_t)in[lane - 1u] : 0x100u;
         uint32_t best_start = 0u, best_len = 0u, best_byte = 0x100u;  // longest extended run so far (none yet)
-        uint32_t best_pair = 0x10000u;                                 // (byte in front of it) | run byte << 8, none yet
         LZ_STAT(0, 1);
         while (p <= mflimit) {
             LZ_STAT(1, 1);
@@ -426,21 +428,25 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                     // still matching: the run reaches the window end and the source run is longer than that
                     Zm = (Zm & ~Lm) | (Lm & ballot(want == to_end) & ballot(best_len > want));
                 }
-                // ... and one byte earlier: "x, then the run" (the '1' in front of a stretch of zeros) copied from the byte
-                // in front of that longest run when it is the same x — the whole "1 0 0 0 ..." becomes ONE match with no
-                // literal, where the default spends two literals and a run match.
-                const unsigned long long Pm0 = LONGRUN ? ballot((d & 0xFFFFu) == best_pair) & (~E >> 1) & (Rm >> 2) & range_m : 0ull;
-                if (LONGRUN && Pm0 != 0ull) {
-                    const uint32_t want = r2 + 2u;                                    // x, the run's first byte, the run
-                    const uint32_t have = best_len + 1u;
-                    const uint32_t lenl = want < have ? want : have;
-                    const unsigned long long Pm = Pm0 & ballot(lenl > lenh);
-                    const bool isl = __builtin_amdgcn_inverse_ballot_w64(Pm);
-                    lenh = isl ? lenl : lenh;
-                    hcand = isl ? best_start - 1u : hcand;
-                    Hm |= Pm;
-                    M |= Pm;
-                    Zm = (Zm & ~Pm) | (Pm & ballot(want == to_end) & ballot(have > want));
+                // ... and every candidate is tried one byte to the left as its left neighbour's candidate (LZ4HC's backward
+                // extension, lane-parallel): if the byte in front of lane+1's source equals this lane's byte, this lane
+                // has a match one byte longer from one byte earlier.  That turns "1, then 0 0 0 ... from the long run"
+                // into one match with no literal, and lengthens ordinary hash matches found one position late.
+                if constexpr (LONGRUN)
+#pragma unroll
+                for (int step = 0; step < LZ_BACK_STEPS; ++step) {
+                    const uint32_t nh = (uint32_t)__builtin_amdgcn_mov_dpp((int)hcand, 0x130, 0xf, 0xf, true);   // lane+1's source
+                    const uint32_t nl = (uint32_t)__builtin_amdgcn_mov_dpp((int)lenh, 0x130, 0xf, 0xf, true);    // ... and length
+                    const uint32_t pbyte = (uint32_t)in[nh ? nh - 1u : 0u];
+                    const unsigned long long Bm = ballot(nl + 1u > lenh) & ballot(nh != 0u) & ballot((d & 0xFFu) == pbyte) & (Hm >> 1) & range_m;
+                    if (Bm != 0ull) {
+                        const bool isb = __builtin_amdgcn_inverse_ballot_w64(Bm);
+                        lenh = isb ? nl + 1u : lenh;
+                        hcand = isb ? nh - 1u : hcand;
+                        Hm |= Bm;
+                        M |= Bm;
+                        Zm = (Zm & ~Bm) | (Bm & (Zm >> 1));
+                    }
                 }
                 const unsigned long long DOMm = (ballot(r1 + 1u > lenh) & (Rm >> 1)) | (ballot(r2 + 2u > lenh) & (Rm >> 2));  // Rm >> k: lane + k starts a run
                 const unsigned long long drop = Hm & (DOMm | ballot(lenh < LZ_MINHASH)) & ~Rm;  // lanes with a run of their own stay candidates
@@ -530,7 +536,6 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                     best_len = ml + 1u;
                     best_start = ps - 1u;
                     best_byte = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)last) & 0xFFu;
-                    best_pair = ps >= 2u ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)in[ps - 2u]) | (best_byte << 8)) : 0x10000u;
                 }
             }
             // next window's own bytes: request now, consumed after the enqueue below
