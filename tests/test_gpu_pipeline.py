@@ -131,3 +131,11 @@ def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
         assert recs["chrom"][0] == b"chr22" and int(recs["start"][0]) == 10012121 and int(recs["stop"][999]) == int(recs["start"][999]) + 1
         if extlibs.have_blosc():
             assert np.array_equal(extlibs.blosc1_decompress(got[d0 + "|chunk|0"], 7488 * 35).view(SNP_DTYPE)[:1000], recs)
+        # and the whole stock read path: libhdf5's filter pipeline with a c-blosc decoder registered for filter 32001
+        from tests.test_h5file import build_blosc_plugin, h5read_filtered
+        plugin = build_blosc_plugin(tmp_path)
+        if plugin is not None:
+            full = h5read_filtered(conv.h5_path, tmp_path, plugin, "chr_22/genotype", "chr_4/genotype", d0)
+            assert np.array_equal(full["chr_22/genotype"], G22) and np.array_equal(full["chr_4/genotype"], o4["G"])
+            assert np.array_equal(full[d0 + "|field|phase1"], G22[1, :, 0]) and np.array_equal(full[d0 + "|field|phase2"], G22[1, :, 1])
+            assert full[d0 + "|field|chrom"][0] == b"chr22" and int(full[d0 + "|field|start"][0]) == 10012121

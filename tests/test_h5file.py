@@ -32,6 +32,29 @@ def h5check(path, tmp_path, *dump):
     return {k: z[k] for k in z.files}
 
 
+def build_blosc_plugin(tmp_path):
+    """-> directory holding the test-built filter-32001 decoder plugin, or None (no compiler / headers / libraries)"""
+    import shutil
+    src = os.path.join(HERE, "h5z_blosc_min.c")
+    if not (shutil.which("gcc") and os.path.exists("/opt/conda/include/hdf5.h") and os.path.exists("/opt/conda/include/blosc.h")):
+        return None
+    d = tmp_path / "h5plugin"
+    d.mkdir(exist_ok=True)
+    r = subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-I/opt/conda/include", src, "-o", str(d / "libh5zbloscmin.so"),
+                        "-L/opt/conda/lib", "-lhdf5", "-lblosc", "-Wl,-rpath,/opt/conda/lib"], capture_output=True, text=True)
+    return str(d) if r.returncode == 0 else None
+
+
+def h5read_filtered(path, tmp_path, plugin_dir, *datasets):
+    """datasets read through libhdf5's filter pipeline (the way h5py + hdf5plugin users read them)"""
+    out = str(tmp_path / "filtered.npz")
+    env = dict(os.environ, HDF5_PLUGIN_PATH=plugin_dir)
+    r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5read_filtered.py"), path, out, *datasets], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
 def test_superblock_and_alignment(tmp_path):
     p = str(tmp_path / "a.h5")
     with h5file.H5Writer(p) as w:
@@ -215,3 +238,32 @@ def test_reader_on_a_file_written_by_libhdf5(tmp_path):
     blk = rd.read_chunk(d, (64, 400, 0)).view(np.int8).reshape(64, 100, 2)
     assert np.array_equal(blk[:6], G[64:70, 400:500])
     rd.close()
+
+
+@needs_h5py
+def test_libhdf5_filter_pipeline_reads_blosc_chunks(tmp_path):
+    """the whole read path of a stock user: libhdf5 walks the chunk B-tree, hands each chunk to filter 32001, the filter
+    (a test-built c-blosc decoder standing in for hdf5plugin) returns the bytes, h5py slices them.  Chunks here come from
+    the CPU oracle's Blosc-1 encoder (the GPU encoder's output goes the same way in tests/test_gpu_pipeline.py)."""
+    plugin = build_blosc_plugin(tmp_path)
+    if plugin is None:
+        pytest.skip("cannot build the filter plugin here")
+    from oracle import oracle
+    S, V, sc, vc = 70, 300, 64, 128
+    rng = np.random.default_rng(11)
+    G = (rng.random((S, V, 2)) < 0.05).astype(np.int8)
+    G[rng.random((S, V, 2)) < 0.003] = -9
+    p = str(tmp_path / "pipe.h5")
+    with h5file.H5Writer(p) as w:
+        chunks = []
+        for si in range(0, S, sc):
+            for vi in range(0, V, vc):
+                blk = np.zeros((sc, vc, 2), np.int8)
+                sub = G[si:si + sc, vi:vi + vc]
+                blk[:sub.shape[0], :sub.shape[1]] = sub
+                ck = oracle.blosc_compress(blk.reshape(-1).view(np.uint8), 2, vc * 2, oracle.BLOSC1)
+                chunks.append(((si, vi, 0), w.append(ck.tobytes(), align=1), ck.size))
+        w.add_chunked("chr_7", "genotype", (S, V, 2), np.int8, (sc, vc, 2), chunks, filter_id=h5file.FILTER_BLOSC,
+                      cd_values=h5file.blosc_cd_values(2, sc * vc * 2), filter_name=b"blosc")
+    got = h5read_filtered(p, tmp_path, plugin, "chr_7/genotype")
+    assert np.array_equal(got["chr_7/genotype"], G)
