@@ -318,6 +318,31 @@ __device__ __forceinline__ void lz4_flush_queue(const uint8_t *in, uint8_t *__re
 // room.  So per-lane predicates live as wave masks in SGPR pairs (v_cmp writes them for free), everything
 // wave-uniform (range limits, the position-0 exclusion, end-of-stream clipping) is scalar and branched
 // around, and the enqueue runs under exec = SEL set by two scalar moves instead of a per-lane test.
+// hash of the NB bytes at a lane's position (own = its six aligned dwords, sh = pos & 3, d = the first four bytes)
+template <int NB>
+__device__ __forceinline__ uint32_t lz4_key_hash(const Own6 &own, uint32_t sh, uint32_t d)
+{
+    if constexpr (NB <= 4) return d * 2654435761u;
+    uint32_t kx = d;
+    constexpr int rot[4] = {13, 7, 21, 27};
+#pragma unroll
+    for (int k = 1; k < (NB + 3) / 4; ++k) {
+        uint32_t e = __builtin_amdgcn_alignbyte(own.w[k + 1], own.w[k], sh);
+        if (k == (NB + 3) / 4 - 1 && (NB & 3)) e &= (1u << (8 * (NB & 3))) - 1u;   // key ends inside this dword
+        kx ^= __builtin_amdgcn_alignbit(e, e, rot[k - 1]);
+    }
+    return kx * 2246822519u;
+}
+
+// Key lengths.  The default mode's single table is keyed on 12 bytes, not LZ4's 4: with a minimum match of 6 the short
+// key only buys candidates that die early, and the most recent place where the next TWELVE bytes were the same is
+// far more often the start of a long match (genotype planes: ratio 4.41 -> 5.12 and 2 % FASTER; 6 / 8 / 10 / 16 / 20 key
+// bytes: 4.60 / 4.85 / 5.01 / 4.77 / 4.54).  A second table with another key length on top (tried: 4..12 with 12..20)
+// added 1 % for 8 ms and was dropped.
+#ifndef LZ_KEY
+#define LZ_KEY 12
+#endif
+
 template <bool FAST, bool LONGRUN>
 __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint32_t n, uint16_t *tab,
                                                          uint32_t hashlog, uint8_t *__restrict__ out, uint2 *queue)
@@ -344,35 +369,13 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             const uint32_t d = __builtin_amdgcn_alignbyte(own.w[1], own.w[0], sh);
             uint32_t hcand = 0u, hsh = 0u;
             Own6 cw;
-            uint32_t hcand2 = 0u, hsh2 = 0u;   // high-effort mode: a second candidate from a table keyed on 12 bytes
-            Own6 cw2;
             if constexpr (!FAST) {
                 // positions past mflimit are inserted too: only the last window has them and nothing reads
                 // the table after it
-                if constexpr (LONGRUN) {
-                    // the table's size does not matter on these planes, so the high-effort mode splits it:
-                    // lower half keyed on 4 bytes as before, upper half keyed on 12 bytes — the most recent place where the
-                    // next TWELVE bytes were the same, i.e. a deeper look into the chain LZ4HC would walk
-                    const uint32_t half = 1u << (hashlog - 1u);
-                    const uint32_t h = (d * 2654435761u) >> (hshift + 1u);
-                    const uint32_t d1 = __builtin_amdgcn_alignbyte(own.w[2], own.w[1], sh);
-                    // 12-byte key (measured: ratio 4.99 / 5.19 / 5.41 / 5.25 / 5.12 with 6 / 8 / 12 / 16 / 20 key bytes)
-                    const uint32_t d2 = __builtin_amdgcn_alignbyte(own.w[3], own.w[2], sh);
-                    const uint32_t kx = d ^ __builtin_amdgcn_alignbit(d1, d1, 13) ^ __builtin_amdgcn_alignbit(d2, d2, 7);
-                    const uint32_t h2 = half + ((kx * 2246822519u) >> (hshift + 1u));
-                    hcand = (uint32_t)tab[h];
-                    hcand2 = (uint32_t)tab[h2];
-                    tab[h] = (uint16_t)pos;
-                    tab[h2] = (uint16_t)pos;
-                    cw = lds_load6(in, hcand);
-                    cw2 = lds_load6(in, hcand2);
-                    hsh2 = hcand2 & 3u;
-                } else {
-                    const uint32_t h = (d * 2654435761u) >> hshift;
-                    hcand = (uint32_t)tab[h];
-                    tab[h] = (uint16_t)pos;
-                    cw = lds_load6(in, hcand);
-                }
+                const uint32_t h = lz4_key_hash<LZ_KEY>(own, sh, d) >> hshift;
+                hcand = (uint32_t)tab[h];
+                tab[h] = (uint16_t)pos;
+                cw = lds_load6(in, hcand);
                 hsh = hcand & 3u;
             }
             // two candidates per position: (a) the hash table's most recent occurrence of these 4 bytes,
@@ -419,24 +422,6 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                 const uint32_t lraw = skip + eq_bytes(t1);
                 lenh = __builtin_amdgcn_inverse_ballot_w64(Hm) ? lraw : 0u;
                 Zm = ballot((x1 | x2 | x3 | x4) == 0u);
-                if constexpr (LONGRUN) {
-                    // same measurement for the 12-byte-key candidate; the longer one wins
-                    const uint32_t y0 = d ^ __builtin_amdgcn_alignbyte(cw2.w[1], cw2.w[0], hsh2);
-                    const uint32_t y1 = __builtin_amdgcn_alignbyte(own.w[2], own.w[1], sh) ^ __builtin_amdgcn_alignbyte(cw2.w[2], cw2.w[1], hsh2);
-                    const uint32_t y2 = __builtin_amdgcn_alignbyte(own.w[3], own.w[2], sh) ^ __builtin_amdgcn_alignbyte(cw2.w[3], cw2.w[2], hsh2);
-                    const uint32_t y3 = __builtin_amdgcn_alignbyte(own.w[4], own.w[3], sh) ^ __builtin_amdgcn_alignbyte(cw2.w[4], cw2.w[3], hsh2);
-                    const uint32_t y4 = __builtin_amdgcn_alignbyte(own.w[5], own.w[4], sh) ^ __builtin_amdgcn_alignbyte(cw2.w[5], cw2.w[4], hsh2);
-                    const uint32_t t2 = y1 ? y1 : (y2 ? y2 : (y3 ? y3 : y4));
-                    const uint32_t skip2 = y1 ? 4u : (y2 ? 8u : (y3 ? 12u : 16u));
-                    const uint32_t len2 = y0 == 0u ? skip2 + eq_bytes(t2) : 0u;
-                    const unsigned long long B2m = ballot(len2 > lenh) & range_m;   // hcand2 < pos like hcand (zeroed table, position 0 masked)
-                    const bool is2 = __builtin_amdgcn_inverse_ballot_w64(B2m);
-                    lenh = is2 ? len2 : lenh;
-                    hcand = is2 ? hcand2 : hcand;
-                    Hm |= B2m;
-                    M |= B2m;
-                    Zm = (Zm & ~B2m) | (B2m & ballot((y1 | y2 | y3 | y4) == 0u));
-                }
             }
             const uint32_t lenr = __builtin_amdgcn_inverse_ballot_w64(Rm) ? run : 0u;
             if constexpr (!FAST) {
