@@ -132,6 +132,10 @@ int hhgt_pad_tail(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_
  *                  (dst_cap >= hhgt_compress_bound(...) always fits).
  * Constraints: 1 <= typesize <= 255; blocksize % typesize == 0; 16 <= blocksize <= 65536 (clamped to the chunk size, as c-blosc does);
  * chunk_nbytes < 2 GiB.
+ * The streams are valid LZ4 blocks for any input, but the match search is tuned to this path's data (byte planes of
+ * genotype matrices, one-hot rows): minimum match 6, hash context of 12 bytes, offset-1 run candidate (csrc/lz4.hip).
+ * format: HHGT_BLOSC1 = the 16-byte-header chunk of c-blosc 1.x, what HDF5 filter 32001 stores; HHGT_BLOSC2 = the
+ * 32-byte extended header of c-blosc2.
  * ------------------------------------------------------------------------------------------- */
 uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize);
 /* Blosc clevel analogue (the reference passes clevel 5: compression_opts[4], vcf_to_h5.py:135).  3..6 (default 5):
