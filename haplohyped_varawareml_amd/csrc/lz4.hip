@@ -504,26 +504,50 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
             //      +14 % / +6 % kernel time: a wave's own serial instruction stream is the limit.  A variant with a
             //      per-lane precomputed "candidates after my match" mask (4 scalar + 2 v_readlane per match) was
             //      slower (36.5 vs 35.4 ms): the readlane -> compare -> branch chain is longer than this one.
-            unsigned long long SEL, mrest;
+            // A match that is still matching after its per-lane cap is finished cooperatively below: in the default mode
+            // only the window's last selected match (the loop ends on it), in the high-effort mode every selected one — a
+            // capped match is NOT followed by its own continuation (the next candidate is the most recent place with the
+            // next 12 bytes, usually somewhere else), so each cut costs a sequence: +3.9 % ratio for +15 % time.
+            // ("+&s": the loop rewrites m while it still needs M — without the early-clobber mark the two, equal on entry,
+            //  may be given the same register pair)
+            unsigned long long SEL = 0ull, mrest = M;
             uint32_t lcur, last;
-            asm volatile("s_mov_b64 %[sel], 0\n\t"
-                         "s_mov_b64 %[m], %[M]\n"
-                         "1:\n\t"
-                         "s_ff1_i32_b64 %[last], %[m]\n\t"
-                         "s_bitset1_b64 %[sel], %[last]\n\t"
-                         "v_readlane_b32 %[lcur], %[len], %[last]\n\t"
-                         "s_add_i32 %[lcur], %[lcur], %[last]\n\t"
-                         "s_cmp_gt_u32 %[lcur], 63\n\t"
-                         "s_cbranch_scc1 2f\n\t"
-                         "s_lshl_b64 %[m], -1, %[lcur]\n\t"
-                         "s_and_b64 %[m], %[m], %[M]\n\t"
-                         "s_cbranch_scc1 1b\n"
-                         "2:"
-                         : [sel] "=&s"(SEL), [m] "=&s"(mrest), [last] "=&s"(last), [lcur] "=&s"(lcur)
-                         : [M] "s"(M), [len] "v"(len)
-                         : "scc");
-            if ((LNG >> last) & 1ull) {
-                // the last match is still matching (36-byte cap, or a run that reaches the window end): finish it
+            for (;;) {
+                if constexpr (LONGRUN) {   // high-effort mode: leave the loop at every selected lane of LNG
+                    asm volatile("1:\n\t"
+                                 "s_ff1_i32_b64 %[last], %[m]\n\t"
+                                 "s_bitset1_b64 %[sel], %[last]\n\t"
+                                 "v_readlane_b32 %[lcur], %[len], %[last]\n\t"
+                                 "s_add_i32 %[lcur], %[lcur], %[last]\n\t"
+                                 "s_bitcmp1_b64 %[lng], %[last]\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_cmp_gt_u32 %[lcur], 63\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_lshl_b64 %[m], -1, %[lcur]\n\t"
+                                 "s_and_b64 %[m], %[m], %[M]\n\t"
+                                 "s_cbranch_scc1 1b\n"
+                                 "2:"
+                                 : [sel] "+&s"(SEL), [m] "+&s"(mrest), [last] "=&s"(last), [lcur] "=&s"(lcur)
+                                 : [M] "s"(M), [len] "v"(len), [lng] "s"(LNG)
+                                 : "scc");
+                } else {                   // default: 8 scalar instructions + one v_readlane per match; only the last match is finished
+                    asm volatile("1:\n\t"
+                                 "s_ff1_i32_b64 %[last], %[m]\n\t"
+                                 "s_bitset1_b64 %[sel], %[last]\n\t"
+                                 "v_readlane_b32 %[lcur], %[len], %[last]\n\t"
+                                 "s_add_i32 %[lcur], %[lcur], %[last]\n\t"
+                                 "s_cmp_gt_u32 %[lcur], 63\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_lshl_b64 %[m], -1, %[lcur]\n\t"
+                                 "s_and_b64 %[m], %[m], %[M]\n\t"
+                                 "s_cbranch_scc1 1b\n"
+                                 "2:"
+                                 : [sel] "+&s"(SEL), [m] "+&s"(mrest), [last] "=&s"(last), [lcur] "=&s"(lcur)
+                                 : [M] "s"(M), [len] "v"(len)
+                                 : "scc");
+                }
+                if (!((LNG >> last) & 1ull)) break;
+                // the selected match is still matching (20-byte cap, or a run that reaches the window end): finish it
                 LZ_STAT(4, 1);
                 const uint32_t ps = p + last;
                 const uint32_t c = ps - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)last);
@@ -562,6 +586,9 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
                     best_start = ps - 1u;
                     best_byte = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)last) & 0xFFu;
                 }
+                if (!LONGRUN || lcur >= 64u) break;   // (default mode: that was the window's last match)
+                mrest = M & (~0ull << lcur);
+                if (mrest == 0ull) break;
             }
             // next window's own bytes: request now, consumed after the enqueue below
             const uint32_t np = p + (lcur > 64u ? lcur : 64u);

@@ -140,7 +140,7 @@ int hhgt_pad_tail(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_
 uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize);
 /* Blosc clevel analogue (the reference passes clevel 5: compression_opts[4], vcf_to_h5.py:135).  3..6 (default 5):
  * hash + run candidates; 1..2: run candidate only (LZ4 "acceleration": faster, lower ratio); 7..9: plus long-run
- * sources and backward extension (about 25 % slower, ~5 % tighter).  Every level emits the same LZ4 block format. */
+ * sources, backward extension and full extension of every match (about 40 % slower, ~10 % tighter).  Every level emits the same LZ4 block format. */
 int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
 int hhgt_compress_chunks(hhgt_ctx *ctx, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
                          int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
