@@ -18,7 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def have_h5py():
     if not os.path.exists(CONDA_PY):
         return False
-    return subprocess.run([CONDA_PY, "-c", "import h5py"], capture_output=True).returncode == 0
+    try:      # bounded: a cold interpreter start may take a minute, a stuck one must not stall the suite
+        return subprocess.run([CONDA_PY, "-c", "import h5py"], capture_output=True, timeout=300).returncode == 0
+    except subprocess.TimeoutExpired:
+        return False
 
 
 needs_h5py = pytest.mark.skipif(not have_h5py(), reason="no independent HDF5 library in this environment")
@@ -26,7 +29,7 @@ needs_h5py = pytest.mark.skipif(not have_h5py(), reason="no independent HDF5 lib
 
 def h5check(path, tmp_path, *dump):
     out = str(tmp_path / "check.npz")
-    r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5check.py"), path, out, *dump], capture_output=True, text=True)
+    r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5check.py"), path, out, *dump], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(out, allow_pickle=False)
     return {k: z[k] for k in z.files}
@@ -41,7 +44,7 @@ def build_blosc_plugin(tmp_path):
     d = tmp_path / "h5plugin"
     d.mkdir(exist_ok=True)
     r = subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-I/opt/conda/include", src, "-o", str(d / "libh5zbloscmin.so"),
-                        "-L/opt/conda/lib", "-lhdf5", "-lblosc", "-Wl,-rpath,/opt/conda/lib"], capture_output=True, text=True)
+                        "-L/opt/conda/lib", "-lhdf5", "-lblosc", "-Wl,-rpath,/opt/conda/lib"], capture_output=True, text=True, timeout=300)
     return str(d) if r.returncode == 0 else None
 
 
@@ -49,7 +52,7 @@ def h5read_filtered(path, tmp_path, plugin_dir, *datasets):
     """datasets read through libhdf5's filter pipeline (the way h5py + hdf5plugin users read them)"""
     out = str(tmp_path / "filtered.npz")
     env = dict(os.environ, HDF5_PLUGIN_PATH=plugin_dir)
-    r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5read_filtered.py"), path, out, *datasets], capture_output=True, text=True, env=env)
+    r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5read_filtered.py"), path, out, *datasets], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(out, allow_pickle=False)
     return {k: z[k] for k in z.files}
@@ -225,7 +228,7 @@ def test_reader_on_a_file_written_by_libhdf5(tmp_path):
         "d[...] = G\n"
         "for i in range(30): f.create_group('many').create_dataset('x%d' % i, data=np.full(2, i, 'u2')) if i == 0 else f['many'].create_dataset('x%d' % i, data=np.full(2, i, 'u2'))\n"
         "f.close()\n")
-    r = subprocess.run([CONDA_PY, "-c", script], capture_output=True, text=True)
+    r = subprocess.run([CONDA_PY, "-c", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
     rd = h5file.H5Reader(p)
     assert sorted(rd.group()) == ["chr_1", "many", "samples"]
