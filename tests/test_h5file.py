@@ -270,3 +270,54 @@ def test_libhdf5_filter_pipeline_reads_blosc_chunks(tmp_path):
                       cd_values=h5file.blosc_cd_values(2, sc * vc * 2), filter_name=b"blosc")
     got = h5read_filtered(p, tmp_path, plugin, "chr_7/genotype")
     assert np.array_equal(got["chr_7/genotype"], G)
+
+
+def test_genotype_store_opens_an_h5_file_cpu(tmp_path):
+    """GenotypeStore over a cohort .h5 (no GPU involved here: metadata, variant tables, raw chunk rows)"""
+    from oracle import oracle
+    from haplohyped_varawareml_amd.store import GenotypeStore
+    S, V, sc, vc = 70, 300, 64, 128
+    rng = np.random.default_rng(21)
+    G = (rng.random((S, V, 2)) < 0.08).astype(np.int8)
+    p = str(tmp_path / "cohort.h5")
+    raw = {}
+    with h5file.H5Writer(p) as w:
+        w.add_array("/", "samples", np.array([f"S{i:03d}".encode() for i in range(S)], dtype="S4"))
+        w.add_array("/", "donor_ids", np.array([b"S001", b"S069"], dtype="S4"))
+        chunks = []
+        for si in range(0, S, sc):
+            for vi in range(0, V, vc):
+                blk = np.zeros((sc, vc, 2), np.int8)
+                sub = G[si:si + sc, vi:vi + vc]
+                blk[:sub.shape[0], :sub.shape[1]] = sub
+                ck = oracle.blosc_compress(blk.reshape(-1).view(np.uint8), 2, vc * 2, oracle.BLOSC1)
+                raw[(si, vi, 0)] = ck
+                chunks.append(((si, vi, 0), w.append(ck.tobytes(), align=1), ck.size))
+        w.add_chunked("chr_7", "genotype", (S, V, 2), np.int8, (sc, vc, 2), chunks, filter_id=h5file.FILTER_BLOSC,
+                      cd_values=h5file.blosc_cd_values(2, sc * vc * 2), filter_name=b"blosc")
+        start = np.sort(rng.integers(1, 1 << 20, V)).astype(np.uint32)
+        w.add_array("chr_7", "start", start)
+        w.add_array("chr_7", "stop", start + 1)
+        w.add_array("chr_7", "ref", np.frombuffer(b"ACGT" * (V // 4), dtype="S1"))
+        w.add_array("chr_7", "alt", np.frombuffer(b"TGCA" * (V // 4), dtype="S1"))
+        w.add_array("chr_7", "chrom_run_first", np.array([0], np.uint32))
+        w.add_array("chr_7", "chrom_run_name", np.array([b"chr7"], dtype="S4"))
+        w.add_array("other", "x", np.zeros(3, np.uint8))          # a group that is not a chromosome
+    st = GenotypeStore(p)
+    assert st.samples[:2] == ["S000", "S001"] and st.meta["donor_ids"] == ["S001", "S069"] and st.groups() == ["chr_7"]
+    g = st.meta["groups"]["chr_7"]
+    assert (st.meta["sc"], st.meta["vc"], st.meta["typesize"], st.meta["blocksize"]) == (sc, vc, 2, vc * 2)
+    assert (g["n_variants"], g["n_vcol"], g["n_scol"], g["n_chunks"]) == (V, 3, 2, 6)
+    s2, ref, alt, runs = st.variants("chr_7")
+    assert np.array_equal(s2, start) and ref.dtype == np.uint8 and bytes(ref[:4]) == b"ACGT" and runs == [[0, "chr7"]]
+    row = st._chunk_row("chr_7", 1)                                    # samples 64..127: three chunks along the variants
+    assert [bytes(r) for r in row] == [raw[(64, v, 0)].tobytes() for v in (0, 128, 256)]
+    # and each of them is what the oracle decodes back to the padded tile
+    tile = oracle.blosc_decompress(np.frombuffer(row[2], np.uint8)).view(np.int8).reshape(sc, vc, 2)
+    assert np.array_equal(tile[:S - 64, :V - 256], G[64:, 256:])
+    st.close()
+    with pytest.raises(ValueError):
+        bad = str(tmp_path / "bad.h5")
+        with h5file.H5Writer(bad) as w:
+            w.add_array("/", "x", np.zeros(1, np.uint8))
+        GenotypeStore(bad)
