@@ -3,8 +3,8 @@
 // Read-side counterpart of lz4.hip/frame.hip: what the HDF5 filter 32001 does when the reference's
 // reader pulls a dataset (/root/reference/src/utils/h5_reader.py:37-41) — and the device-side half of
 // the encode -> compress -> decode round-trip property used by the full-size parity tests.
-// Workgroup = one block; wave j decodes stream j from a staged LDS copy of its compressed bytes into
-// its LDS plane; the workgroup then un-shuffles the planes straight into HBM with 16 B stores.
+// Workgroup = one block; wave j decodes stream j in place: compressed bytes staged at the end of its LDS
+// plane buffer, decoded bytes written from the start; the workgroup then un-shuffles the planes straight into HBM with 16 B stores.
 #include "common.h"
 
 #define BLOSC_DOSHUFFLE 0x1u
@@ -12,10 +12,13 @@
 #define BLOSC_DOBITSHUFFLE 0x4u
 #define BLOSC_DONT_SPLIT 0x10u
 
-__device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
-{
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+// little-endian u32 at any byte address of GLOBAL memory (one unaligned dword load, not four byte loads)
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { return *reinterpret_cast<const u32_unaligned *>(p); }
+
+// a value every lane holds identically, moved to an SGPR: everything derived from it (ip, op, lengths, the
+// branches on them) then compiles to scalar code instead of exec-masked vector code
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // LZ4 length extension starting at cin[ip]: returns added length, advances ip. wave-uniform.
 __device__ __forceinline__ bool read_ext(const uint8_t *cin, uint32_t csize, uint32_t &ip, uint32_t &len)
@@ -31,11 +34,38 @@ __device__ __forceinline__ bool read_ext(const uint8_t *cin, uint32_t csize, uin
             if (ip >= csize) return false;
             continue;
         }
-        const uint32_t j = (uint32_t)__ffsll((long long)stop) - 1u;
+        const uint32_t j = (uint32_t)__builtin_ctzll(stop);
         if (ip + j >= csize) return false;
         len += 255u * j + (uint32_t)__builtin_amdgcn_readlane((int)b, (int)j);
         ip += j + 1u;
         return true;
+    }
+}
+
+// out[op, op + ml) = the ml bytes starting `off` back (all arguments but lane wave-uniform, off >= 1)
+__device__ __forceinline__ void lz4_match_copy(uint8_t *out, uint32_t op, uint32_t off, uint32_t ml, uint32_t lane)
+{
+    if (off >= 64u || ml <= off) {
+        // 64-byte steps never read bytes written in the same step
+        if (lane < ml) out[op + lane] = out[op + lane - off];
+        if (ml > 64u)
+            for (uint32_t k = lane + 64u; k < ml; k += 64u) out[op + k] = out[op + k - off];
+        return;
+    }
+    // overlapping match = periodic extension of the last `off` bytes
+    const uint8_t *pat = out + op - off;
+    uint32_t ph, step;
+    if ((off & (off - 1u)) == 0u) {  // runs of a byte / pair / quad: the usual case, no division
+        ph = lane & (off - 1u);
+        step = 0u;
+    } else {
+        ph = lane % off;
+        step = 64u % off;
+    }
+    for (uint32_t k = lane; k < ml; k += 64u) {
+        out[op + k] = pat[ph];
+        ph += step;
+        if (ph >= off) ph -= off;
     }
 }
 
@@ -46,7 +76,42 @@ __device__ __forceinline__ bool lz4_wave_decode(const uint8_t *cin, uint32_t csi
     uint32_t ip = 0, op = 0;
     for (;;) {
         if (ip >= csize) return false;
-        const uint32_t token = cin[ip++];
+        // Fast path (nearly every sequence of a genotype plane): token, up to 13 literals, the offset and one match-length
+        // extension byte all sit in the 19 bytes at ip.  Lane k (k <= 15) gathers the two aligned dwords around byte
+        // ip + k and forms the 32-bit window starting there, so every header field is one readlane away: the token
+        // from lane 0, offset + extension byte from lane ll + 1; byte 1 of lane k's window is literal k.  The kernel
+        // is bound by scalar-ALU issue (one SALU op per cycle per CU, shared by all its waves), so the point of this
+        // shape is few scalar instructions per sequence.  (cin has >= 24 readable bytes past csize.)
+        {
+            const uint32_t q = ip + (lane < 15u ? lane : 15u);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(cin) + (q >> 2);
+            const uint32_t v = __builtin_amdgcn_alignbyte(w[1], w[0], q & 3u);         // bytes ip + lane .. + 3
+            const uint32_t t = uni(v);
+            const uint32_t ll = (t >> 4) & 15u, mlt = t & 15u;
+            if (ll <= 13u) {
+                const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(ll + 1u));
+                const uint32_t off = s3 & 0xFFFFu;
+                uint32_t ml = mlt + 4u, adv = ll + 3u;
+                bool plain = true;
+                if (mlt == 15u) {              // lengths 19..273: one extension byte; 255 = longer, general path below
+                    const uint32_t e1 = (s3 >> 16) & 0xFFu;
+                    ml += e1;
+                    adv += 1u;
+                    plain = e1 != 255u;
+                }
+                // whole sequence inside the stream (so this is not the literal-only last one), output fits, offset
+                // reaches no further back than the first byte; anything else is sorted out by the general path
+                if (plain && ip + adv <= csize && ll + ml <= n - op && off - 1u < op + ll) {
+                    if (lane < ll) out[op + lane] = (uint8_t)(v >> 8);
+                    op += ll;
+                    lz4_match_copy(out, op, off, ml, lane);
+                    op += ml;
+                    ip += adv;
+                    continue;
+                }
+            }
+        }
+        const uint32_t token = uni(cin[ip++]);
         uint32_t ll = token >> 4;
         if (ll == 15u && !read_ext(cin, csize, ip, ll)) return false;
         if (ll > csize - ip || ll > n - op) return false;
@@ -55,43 +120,30 @@ __device__ __forceinline__ bool lz4_wave_decode(const uint8_t *cin, uint32_t csi
         ip += ll;
         if (ip == csize) break;  // last sequence carries literals only
         if (csize - ip < 2u) return false;
-        const uint32_t off = (uint32_t)cin[ip] | ((uint32_t)cin[ip + 1u] << 8);
+        const uint32_t off = uni((uint32_t)cin[ip] | ((uint32_t)cin[ip + 1u] << 8));
         ip += 2u;
         if (off == 0u || off > op) return false;
         uint32_t ml = token & 15u;
         if (ml == 15u && !read_ext(cin, csize, ip, ml)) return false;
         ml += 4u;
         if (ml > n - op) return false;
-        if (off >= 64u) {
-            // 64-byte steps never read bytes written in the same step
-            for (uint32_t k = lane; k < ml; k += 64u) out[op + k] = out[op + k - off];
-        } else {
-            // overlapping match = periodic extension of the last `off` bytes
-            const uint8_t *pat = out + op - off;
-            uint32_t ph = lane % off;
-            const uint32_t step = 64u % off;
-            for (uint32_t k = lane; k < ml; k += 64u) {
-                out[op + k] = pat[ph];
-                ph += step;
-                if (ph >= off) ph -= off;
-            }
-        }
+        lz4_match_copy(out, op, off, ml, lane);
         op += ml;
     }
     return op == n;
 }
 
-// grid = n_chunks * nblocks; block = 64 * nwaves; dynamic LDS = nwaves * (pstride + cstride) + 32
+// grid = n_chunks * nblocks; block = 64 * nwaves; dynamic LDS = nwaves * sstride + 16
 __global__ __launch_bounds__(1024) void k_decode_blocks(const uint8_t *__restrict__ src,
                                                         const unsigned long long *__restrict__ chunk_off,
                                                         uint32_t nblocks, uint64_t chunk_nbytes, uint32_t typesize,
-                                                        uint32_t blocksize, uint32_t sstride, uint32_t cstride,
+                                                        uint32_t blocksize, uint32_t sstride,
                                                         uint8_t *__restrict__ dst, unsigned long long *n_bad)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_bad;
     const uint32_t nwaves = blockDim.x >> 6;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;  // SGPR: stream sizes and LDS bases follow
     const uint64_t chunk = blockIdx.x / nblocks;
     const uint32_t b = blockIdx.x - (uint32_t)(chunk * nblocks);
     const uint8_t *ck = src + chunk_off[chunk];
@@ -146,7 +198,8 @@ __global__ __launch_bounds__(1024) void k_decode_blocks(const uint8_t *__restric
     const uint32_t neblock = bsize / nstreams;
     const uint32_t pstride = nstreams > 1u ? sstride : nelem;
     uint8_t *planes = smem;
-    uint8_t *cbuf = smem + (size_t)nwaves * sstride + 16u;
+    // bytes of LDS the stream of this wave owns: its plane, or the whole area when the block is one stream
+    const uint32_t cap = nstreams > 1u ? sstride : nwaves * sstride;
     // stream table of this block: walk the csize words (nstreams <= 16, serial by every thread)
     const uint32_t bstart = ld32u(ck + hl + 4u * b);
     uint32_t sp = bstart, my_sp = 0, my_cs = 0;
@@ -172,9 +225,19 @@ __global__ __launch_bounds__(1024) void k_decode_blocks(const uint8_t *__restric
         if (my_cs == neblock) {
             for (uint32_t k = lane; k < neblock; k += 64u) plane[k] = ck[my_sp + k];
         } else {
-            uint8_t *cin = cbuf + (size_t)wave * cstride;
-            for (uint32_t k = lane; k < my_cs; k += 64u) cin[k] = ck[my_sp + k];
-            if (!lz4_wave_decode(cin, my_cs, plane, neblock)) sbad = true;
+            // In-place decode (lz4.h's LZ4_DECOMPRESS_INPLACE_MARGIN scheme): the compressed bytes are staged at the
+            // END of the plane's own buffer and the decoder writes from its start.  In a valid block the bytes still to
+            // read never exceed the bytes still to write by more than 2 + n/255, so with a margin of (n >> 8) + 32 the
+            // write head stays behind the read head; a malformed block can only garble its own output, every access
+            // stays inside [plane, plane + cap).  Halves the LDS per workgroup -> 16 instead of 9 workgroups per CU.
+            if (neblock + (neblock >> 8) + 60u > cap) sbad = true;
+            uint8_t *cin = plane + ((cap - 24u - my_cs) & ~3u);   // dword-aligned; 24 readable bytes behind the stream
+            const uint32_t nd = my_cs >> 2;       // whole dwords (unaligned global loads), then the last 1-3 bytes
+            if (!sbad) {
+                for (uint32_t k = lane; k < nd; k += 64u) reinterpret_cast<uint32_t *>(cin)[k] = ld32u(ck + my_sp + 4u * k);
+                if (lane < (my_cs & 3u)) cin[4u * nd + lane] = ck[my_sp + 4u * nd + lane];
+            }
+            if (sbad || !lz4_wave_decode(cin, my_cs, plane, neblock)) sbad = true;
         }
     }
     if (sbad) atomicOr(&s_bad, 1u);
@@ -220,16 +283,13 @@ int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_
     const uint32_t nwaves = split ? (uint32_t)typesize : 1u;
     const uint32_t nblocks = (uint32_t)((chunk_nbytes + blocksize - 1) / blocksize);
     const uint32_t max_stream = split ? (uint32_t)blocksize / (uint32_t)typesize : (uint32_t)blocksize;
-    uint32_t sstride = (max_stream + 8u + 15u) & ~15u;
-    if (split && chunk_nbytes % blocksize) {
-        uint32_t need = ((uint32_t)(chunk_nbytes % blocksize) + 8u + 15u) & ~15u;
-        if (need > sstride * nwaves) sstride = (need + nwaves - 1) / nwaves;
-        sstride = (sstride + 15u) & ~15u;
+    // per-stream buffer = decoded plane + in-place margin ((n >> 8) + 32) + alignment slack (4) + read-ahead (24)
+    uint32_t sstride = (max_stream + (max_stream >> 8) + 60u + 15u) & ~15u;
+    {   // a block decoded as ONE stream (no-split header, or the short last block of a chunk) owns the whole area
+        const uint32_t whole = (uint32_t)blocksize + ((uint32_t)blocksize >> 8) + 60u;
+        if (whole > sstride * nwaves) sstride = ((whole + nwaves - 1) / nwaves + 15u) & ~15u;
     }
-    // compressed staging: a stream never exceeds its decoded size; the leftover/no-split stream of a
-    // split launch is staged across the whole staging area
-    uint32_t cstride = sstride;
-    const size_t lds = (size_t)nwaves * sstride + 16u + (size_t)nwaves * cstride + 16u;
+    const size_t lds = (size_t)nwaves * sstride + 16u;
     if (lds > 160 * 1024 - 64) {
         hhgt_set_error("decode: block of %d bytes x typesize %d does not fit LDS", blocksize, typesize);
         return HHGT_ERR_ARG;
@@ -247,7 +307,7 @@ int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_
     }
     hipLaunchKernelGGL(k_decode_blocks, dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src,
                        reinterpret_cast<const unsigned long long *>(d_chunk_off), nblocks, chunk_nbytes,
-                       (uint32_t)typesize, (uint32_t)blocksize, sstride, cstride, d_dst, d_bad);
+                       (uint32_t)typesize, (uint32_t)blocksize, sstride, d_dst, d_bad);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

@@ -17,11 +17,14 @@ dst, off, total = ctx.compress(res.G, chunk, typesize=2, blocksize=dev.DEFAULT_B
 back, bad = ctx.decompress(dst, off, n_chunks, chunk, typesize=2, blocksize=dev.DEFAULT_BLOCKSIZE)
 assert bad == 0 and torch.equal(back, res.G)
 torch.cuda.synchronize()
+ctx.profile(True)
+ctx.profile_reset()
 t0 = time.perf_counter()
 N = 5
 for _ in range(N):
     back, bad = ctx.decompress(dst, off, n_chunks, chunk, typesize=2, blocksize=dev.DEFAULT_BLOCKSIZE)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
-print(json.dumps(dict(variants=V, samples=S, raw_GB=res.G.numel() / 1e9, compressed_GB=total / 1e9, ms=dt * 1e3,
-                      out_GBps=res.G.numel() / dt / 1e9, variants_per_s=V / dt)))
+kern = ctx.profile_read().get("decode", {"ms": 0.0})["ms"] / N
+print(json.dumps(dict(variants=V, samples=S, raw_GB=res.G.numel() / 1e9, compressed_GB=total / 1e9, ms_call=dt * 1e3, ms_kernel=kern,
+                      out_GBps_kernel=res.G.numel() / (kern * 1e-3) / 1e9 if kern else None, variants_per_s=V / dt)))
