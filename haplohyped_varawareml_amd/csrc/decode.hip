@@ -75,7 +75,6 @@ __device__ __forceinline__ bool lz4_wave_decode(const uint8_t *cin, uint32_t csi
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t ip = 0, op = 0;
     for (;;) {
-        if (ip >= csize) return false;
         // Fast path (nearly every sequence of a genotype plane): token, up to 13 literals, the offset and one match-length
         // extension byte all sit in the 19 bytes at ip.  Lane k (k <= 15) gathers the two aligned dwords around byte
         // ip + k and forms the 32-bit window starting there, so every header field is one readlane away: the token
@@ -91,17 +90,13 @@ __device__ __forceinline__ bool lz4_wave_decode(const uint8_t *cin, uint32_t csi
             if (ll <= 13u) {
                 const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(ll + 1u));
                 const uint32_t off = s3 & 0xFFFFu;
-                uint32_t ml = mlt + 4u, adv = ll + 3u;
-                bool plain = true;
-                if (mlt == 15u) {              // lengths 19..273: one extension byte; 255 = longer, general path below
-                    const uint32_t e1 = (s3 >> 16) & 0xFFu;
-                    ml += e1;
-                    adv += 1u;
-                    plain = e1 != 255u;
-                }
+                // lengths 19..273 carry one extension byte (255 there = longer still: general path below); branch-free
+                const uint32_t is15 = (mlt + 1u) >> 4;
+                const uint32_t e1 = ((s3 >> 16) & 0xFFu) * is15;
+                const uint32_t ml = mlt + 4u + e1, adv = ll + 3u + is15;
                 // whole sequence inside the stream (so this is not the literal-only last one), output fits, offset
                 // reaches no further back than the first byte; anything else is sorted out by the general path
-                if (plain && ip + adv <= csize && ll + ml <= n - op && off - 1u < op + ll) {
+                if (e1 != 255u && ip + adv <= csize && ll + ml <= n - op && off - 1u < op + ll) {
                     if (lane < ll) out[op + lane] = (uint8_t)(v >> 8);
                     op += ll;
                     lz4_match_copy(out, op, off, ml, lane);
@@ -111,6 +106,7 @@ __device__ __forceinline__ bool lz4_wave_decode(const uint8_t *cin, uint32_t csi
                 }
             }
         }
+        if (ip >= csize) return false;  // (the fast path cannot pass its own bounds check from here either)
         const uint32_t token = uni(cin[ip++]);
         uint32_t ll = token >> 4;
         if (ll == 15u && !read_ext(cin, csize, ip, ll)) return false;
