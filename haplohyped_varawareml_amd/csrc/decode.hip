@@ -50,22 +50,24 @@ __device__ __forceinline__ void lz4_match_copy(uint8_t *out, uint32_t op, uint32
         if (lane < ml) out[op + lane] = out[op + lane - off];
         if (ml > 64u)
             for (uint32_t k = lane + 64u; k < ml; k += 64u) out[op + k] = out[op + k - off];
-        return;
-    }
-    // overlapping match = periodic extension of the last `off` bytes
-    const uint8_t *pat = out + op - off;
-    uint32_t ph, step;
-    if ((off & (off - 1u)) == 0u) {  // runs of a byte / pair / quad: the usual case, no division
-        ph = lane & (off - 1u);
-        step = 0u;
     } else {
-        ph = lane % off;
-        step = 64u % off;
-    }
-    for (uint32_t k = lane; k < ml; k += 64u) {
-        out[op + k] = pat[ph];
-        ph += step;
-        if (ph >= off) ph -= off;
+        // overlapping match = periodic extension of the last `off` bytes
+        const uint8_t *pat = out + op - off;
+        uint32_t ph, step;
+        if ((off & (off - 1u)) == 0u) {  // runs of a byte / pair / quad: the usual case, no division
+            ph = lane & (off - 1u);
+            step = 0u;
+        } else {
+            ph = lane % off;
+            step = 64u % off;
+        }
+        if (lane < ml) out[op + lane] = pat[ph];
+        if (ml > 64u)
+            for (uint32_t k = lane + 64u; k < ml; k += 64u) {
+                ph += step;
+                if (ph >= off) ph -= off;
+                out[op + k] = pat[ph];
+            }
     }
 }
 
