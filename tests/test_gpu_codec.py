@@ -108,6 +108,31 @@ def test_gpu_decoder_reads_oracle_chunks(ctx):
         assert bad == 0 and np.array_equal(back.cpu().numpy(), data)
 
 
+@pytest.mark.parametrize("typesize,blocksize,tail", [(2, 8192, 0), (2, 8192, 3000), (1, 8192, 0), (4, 16384, 1234)])
+def test_gpu_decoder_in_place_margin(ctx, typesize, blocksize, tail):
+    """The decoder works in place (compressed bytes at the end of the plane's LDS buffer).  Worst case for that
+    scheme: streams that barely compress — a short run, then literals to the end with every length-extension byte —
+    so the read head leads the write head by the smallest margin LZ4 allows.  Streams are the oracle's (a foreign
+    encoder), in both orders (run first / run last), plus a short last block decoded as one stream."""
+    rng = np.random.default_rng(77)
+    nblk = 6
+    for run_first in (True, False):
+        for run in (48, 64, 100, 255, 700):
+            planes = rng.integers(0, 256, size=(nblk, typesize, blocksize // typesize), dtype=np.uint8)
+            if run_first:
+                planes[:, :, :run] = 7
+            else:
+                planes[:, :, -run:] = 7
+            body = np.ascontiguousarray(planes.transpose(0, 2, 1)).reshape(-1)      # un-shuffled element order
+            data = np.concatenate([body, rng.integers(0, 4, size=tail, dtype=np.uint8)])
+            for fmt in (oracle.BLOSC1, oracle.BLOSC2):
+                ck = oracle.blosc_compress(data, typesize, blocksize, fmt)
+                assert ck.size < data.size + 64
+                off = torch.tensor([0, ck.size], dtype=torch.int64, device="cuda")
+                back, bad = ctx.decompress(to_dev(ck), off, 1, data.size, typesize=typesize, blocksize=blocksize)
+                assert bad == 0 and np.array_equal(back.cpu().numpy(), data), (run_first, run, fmt)
+
+
 def test_gpu_decoder_flags_corruption(ctx):
     data = genotype_like(4, 4096, 9).reshape(-1).view(np.uint8)
     ck = oracle.blosc_compress(data, 2, 8192, oracle.BLOSC2).copy()
