@@ -45,29 +45,31 @@ __device__ __forceinline__ bool read_ext(const uint8_t *cin, uint32_t csize, uin
 // out[op, op + ml) = the ml bytes starting `off` back (all arguments but lane wave-uniform, off >= 1)
 __device__ __forceinline__ void lz4_match_copy(uint8_t *out, uint32_t op, uint32_t off, uint32_t ml, uint32_t lane)
 {
-    if (off >= 64u || ml <= off) {
-        // 64-byte steps never read bytes written in the same step
-        if (lane < ml) out[op + lane] = out[op + lane - off];
-        if (ml > 64u)
-            for (uint32_t k = lane + 64u; k < ml; k += 64u) out[op + k] = out[op + k - off];
-    } else {
-        // overlapping match = periodic extension of the last `off` bytes
-        const uint8_t *pat = out + op - off;
-        uint32_t ph, step;
+    // byte k of the match is byte (k mod off) of the `off` bytes before op once the match overlaps itself, byte k of
+    // them otherwise; one straight-line step serves the first 64 bytes of every case (a 64-byte step never reads a
+    // byte written in the same step), the loop behind it is only entered by matches longer than that
+    const uint8_t *pat = out + op - off;
+    uint32_t ph = lane, step = 0u;
+    if ((ml < 64u ? ml : 64u) > off) {  // off < 64 and ml > off: the match overlaps itself within a step
         if ((off & (off - 1u)) == 0u) {  // runs of a byte / pair / quad: the usual case, no division
             ph = lane & (off - 1u);
-            step = 0u;
         } else {
             ph = lane % off;
             step = 64u % off;
         }
-        if (lane < ml) out[op + lane] = pat[ph];
-        if (ml > 64u)
+    }
+    if (lane < ml) out[op + lane] = pat[ph];
+    if (ml > 64u) {
+        asm volatile("" ::: "memory");  // keep the (scalar) length test: the loop guard alone would cost every sequence
+        if (off < 64u) {
             for (uint32_t k = lane + 64u; k < ml; k += 64u) {
                 ph += step;
                 if (ph >= off) ph -= off;
                 out[op + k] = pat[ph];
             }
+        } else {
+            for (uint32_t k = lane + 64u; k < ml; k += 64u) out[op + k] = pat[k];
+        }
     }
 }
 
