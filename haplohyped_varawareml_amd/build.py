@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhhgt.so")
-SOURCES = ["scan.hip", "index.hip", "encode.hip", "lz4.hip", "frame.hip", "decode.hip", "synth.hip",
+SOURCES = ["scan.hip", "index.hip", "encode.hip", "lz4.hip", "frame.hip", "decode.hip", "inflate.hip", "synth.hip",
            "reader.hip", "onehot.hip", "api.hip"]
 
 

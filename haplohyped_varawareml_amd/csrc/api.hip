@@ -553,6 +553,44 @@ extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)
     return HHGT_OK;
 }
 
+__global__ void k_count_nonzero_u32(const uint32_t *__restrict__ v, uint64_t n, unsigned long long *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && v[i] != 0u);
+    if ((threadIdx.x & 63u) == 0u && m) atomicAdd(out, (unsigned long long)__builtin_popcountll(m));
+}
+
+extern "C" int hhgt_inflate_members(hhgt_ctx *c, const void *d_src, uint64_t src_bytes, const uint64_t *d_comp_off,
+                                    const uint32_t *d_comp_len, const uint64_t *d_out_off, const uint32_t *d_isize,
+                                    uint64_t n_members, void *d_dst, uint64_t dst_bytes, uint32_t *d_status,
+                                    uint64_t *n_bad, void *stream)
+{
+    if (!c || !d_src || !d_comp_off || !d_comp_len || !d_out_off || !d_isize || !d_status || (!d_dst && dst_bytes))
+        return HHGT_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_bad) *n_bad = 0;
+    if (n_members == 0) return HHGT_OK;
+    {
+        StageTimer t(c, st, HHGT_STAGE_INFLATE);
+        TRY(launch_inflate(static_cast<const uint8_t *>(d_src), src_bytes, d_comp_off, d_comp_len, d_out_off, d_isize,
+                           n_members, static_cast<uint8_t *>(d_dst), dst_bytes, d_status, st));
+        t.stop();
+    }
+    if (n_bad) {
+        TRY(c->dec_bad.ensure(8));
+        HIP_TRY(hipMemsetAsync(c->dec_bad.p, 0, 8, st));
+        hipLaunchKernelGGL(k_count_nonzero_u32, dim3((uint32_t)((n_members + 255) / 256)), dim3(256), 0, st, d_status,
+                           n_members, c->dec_bad.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        uint64_t nb = 0;
+        HIP_TRY(hipMemcpyAsync(&nb, c->dec_bad.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *n_bad = nb;
+    }
+    return HHGT_OK;
+}
+
 extern "C" int hhgt_decompress_chunks(hhgt_ctx *c, const void *d_src, const uint64_t *d_chunk_off, uint64_t n_chunks,
                                       uint64_t chunk_nbytes, int typesize, int blocksize, void *d_dst,
                                       uint64_t *n_bad, void *stream)

@@ -161,6 +161,9 @@ int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_
                  uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st);
 int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_chunks, uint64_t chunk_nbytes,
                   int typesize, int blocksize, uint8_t *d_dst, unsigned long long *d_bad, hipStream_t st);
+int launch_inflate(const uint8_t *d_src, uint64_t src_bytes, const uint64_t *d_comp_off, const uint32_t *d_comp_len,
+                   const uint64_t *d_out_off, const uint32_t *d_isize, uint64_t n_members, uint8_t *d_dst,
+                   uint64_t dst_bytes, uint32_t *d_status, hipStream_t st);
 
 // layout helper shared by host and device
 static inline __host__ __device__ uint64_t layout_offset(const LayoutDev &L, uint32_t s, uint64_t v)

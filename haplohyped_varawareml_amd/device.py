@@ -66,6 +66,32 @@ class EncodeResult:
         return g.reshape(n_sc * Sc, n_vc * Vc, 2)[:S, :n]
 
 
+def bgzf_scan(raw):
+    """Member table of a BGZF byte string (host only; `hhgt_bgzf_scan`).  -> dict(data, comp_off, comp_len, isize,
+    consumed): offsets / lengths of the raw DEFLATE payloads, inflated sizes, bytes covered by whole members."""
+    from ._lib import load
+    lib = load()
+    data = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray, memoryview)) else np.ascontiguousarray(raw, dtype=np.uint8)
+    offs, lens, isz = [], [], []
+    pos, cap = 0, 1 << 16
+    while pos < data.size:
+        co = np.zeros(cap, dtype=np.uint64)
+        cl = np.zeros(cap, dtype=np.uint32)
+        iz = np.zeros(cap, dtype=np.uint32)
+        n, used = C.c_uint64(0), C.c_uint64(0)
+        check(lib.hhgt_bgzf_scan(C.c_void_p(data.ctypes.data + pos), data.size - pos, cap, C.c_void_p(co.ctypes.data),
+                                 C.c_void_p(cl.ctypes.data), C.c_void_p(iz.ctypes.data), C.byref(n), C.byref(used)))
+        if n.value == 0:
+            break
+        offs.append(co[:n.value] + np.uint64(pos))
+        lens.append(cl[:n.value])
+        isz.append(iz[:n.value])
+        pos += used.value
+    cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+    return dict(data=data, comp_off=cat(offs, np.uint64), comp_len=cat(lens, np.uint32), isize=cat(isz, np.uint32),
+                consumed=pos)
+
+
 class Context:
     """One per (process, GPU).  Wraps hhgt_ctx."""
 
@@ -182,6 +208,33 @@ class Context:
                                                   int(chunk_nbytes), typesize, blocksize, _ptr(dst),
                                                   C.byref(bad), _stream()))
         return dst, int(bad.value)
+
+    # ---- BGZF on the device -------------------------------------------------------
+    def inflate_bgzf(self, raw, return_status=False):
+        """raw: host bytes / uint8 array holding whole BGZF members.  The host walks the member headers
+        (bgzf_scan), the compressed bytes are uploaded as they are and every member is inflated by one wave.
+        -> (text uint8 tensor on the device, n_bad[, status tensor])"""
+        tab = bgzf_scan(raw)
+        host = tab["data"]
+        n = len(tab["isize"])
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(tab["isize"], dtype=np.uint64, out=out_off[1:])
+        total = int(out_off[-1])
+        with torch.cuda.device(self.device):
+            padded = np.zeros((host.size + 3) // 4 * 4 + 4, dtype=np.uint8)
+            padded[:host.size] = host
+            d_src = torch.from_numpy(padded).to(self.device)
+            d_off = torch.from_numpy(tab["comp_off"]).to(self.device)
+            d_len = torch.from_numpy(tab["comp_len"]).to(self.device)
+            d_out = torch.from_numpy(out_off[:-1].copy()).to(self.device)
+            d_isz = torch.from_numpy(tab["isize"]).to(self.device)
+            dst = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)[:total]
+            status = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)[:n]
+            bad = C.c_uint64(0)
+            check(self.lib.hhgt_inflate_members(self.h, _ptr(d_src), padded.size, _ptr(d_off), _ptr(d_len), _ptr(d_out),
+                                                _ptr(d_isz), n, _ptr(dst), total, _ptr(status), C.byref(bad),
+                                                _stream()))
+        return (dst, int(bad.value), status) if return_status else (dst, int(bad.value))
 
     # ---- synthetic workloads (bench / test tooling) -----------------------------------------------
     def synth_fixed(self, contig, table, n_samples, seed, v_first=0, with_header=True, names=None):

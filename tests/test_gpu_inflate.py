@@ -1,0 +1,114 @@
+"""-m gpu: BGZF members inflated on the device (`hhgt_inflate_members`) against zlib.
+Bar: byte-exact text for every member; stored, fixed-Huffman and dynamic-Huffman blocks, empty members,
+64 KiB members, overlapping matches of every short distance; corrupt members are flagged, not crashed on."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from haplohyped_varawareml_amd import device as dev, synth
+from haplohyped_varawareml_amd.reader import write_bgzf
+
+pytestmark = pytest.mark.gpu
+
+
+def bgzf(chunks, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    out = []
+    for c in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        comp = co.compress(c) + co.flush()
+        assert len(comp) + 26 <= 65536
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                   struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+    return b"".join(out)
+
+
+def split(data, n):
+    return [data[i:i + n] for i in range(0, len(data), n)]
+
+
+def check(ctx, raw, want):
+    text, bad, status = ctx.inflate_bgzf(raw, return_status=True)
+    assert bad == 0, status.cpu().numpy()[status.cpu().numpy() != 0][:8]
+    got = text.cpu().numpy().tobytes()
+    assert len(got) == len(want)
+    if got != want:
+        a, b = np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)
+        i = int(np.flatnonzero(a != b)[0])
+        raise AssertionError(f"first difference at byte {i} of {len(want)}: got {got[i-8:i+8]!r} want {want[i-8:i+8]!r}")
+
+
+def vcf_like(n_lines, S, seed):
+    rng = np.random.default_rng(seed)
+    lines = [b"##fileformat=VCFv4.2\n", b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + b"\t".join(b"S%d" % i for i in range(S)) + b"\n"]
+    calls = np.array([b"0|0", b"0|1", b"1|0", b"1|1", b".|."])
+    for i in range(n_lines):
+        g = calls[rng.choice(5, size=S, p=[0.9, 0.04, 0.04, 0.015, 0.005])]
+        lines.append(b"chr1\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t" % (1000 + 37 * i, i) + b"\t".join(g) + b"\n")
+    return b"".join(lines)
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_vcf_text_members(ctx, level):
+    text = vcf_like(400, 500, 5)
+    check(ctx, bgzf(split(text, 0xFF00), level), text)
+
+
+def test_fixed_huffman_and_stored_blocks(ctx):
+    text = vcf_like(60, 300, 6)
+    check(ctx, bgzf(split(text, 20000), 6, zlib.Z_FIXED), text)             # BTYPE 1
+    check(ctx, bgzf(split(text, 20000), 0), text)                          # BTYPE 0 (level 0: stored blocks only)
+    rnd = bytes(np.random.default_rng(1).integers(0, 256, size=150_000, dtype=np.uint8))
+    check(ctx, bgzf(split(rnd, 60000), 6), rnd)                             # zlib falls back to stored blocks
+    check(ctx, bgzf(split(rnd, 60000), 6, zlib.Z_HUFFMAN_ONLY), rnd)        # literals only, 8/9-bit codes
+
+
+def test_overlapping_matches_every_distance(ctx):
+    rng = np.random.default_rng(8)
+    parts = []
+    for d in list(range(1, 70)) + [127, 128, 129, 255, 256, 1000, 4097, 32768]:
+        unit = bytes(rng.integers(65, 91, size=d, dtype=np.uint8))
+        parts.append((unit * (700 // d + 3))[:700 + d])
+        parts.append(bytes(rng.integers(0, 256, size=13, dtype=np.uint8)))
+    text = b"".join(parts)
+    check(ctx, bgzf(split(text, 65000), 9), text)
+
+
+def test_member_shapes(ctx):
+    chunks = [b"", b"x", b"ab" * 3, b"\n" * 65536, bytes(range(256)) * 256, b"", vcf_like(5, 20, 2)]
+    assert len(chunks[3]) == 65536 and len(chunks[4]) == 65536
+    check(ctx, bgzf(chunks), b"".join(chunks))
+    many = [b"line %d\n" % i for i in range(3000)]                          # more members than one launch wave-set
+    check(ctx, bgzf(many, 6), b"".join(many))
+
+
+def test_writer_file_roundtrip(ctx, tmp_path):
+    tab = synth.variant_table(11, 2000, 64)
+    text_dev, _ = ctx.synth_fixed("chr1", tab, 64, seed=11)
+    text = text_dev.cpu().numpy().tobytes()
+    path = tmp_path / "s.vcf.gz"
+    write_bgzf(str(path), text)
+    check(ctx, path.read_bytes(), text)
+
+
+def test_corrupt_members_are_flagged(ctx):
+    text = vcf_like(300, 400, 9)
+    raw = bytearray(bgzf(split(text, 0xFF00), 6))
+    tab = dev.bgzf_scan(bytes(raw))
+    n = len(tab["isize"])
+    assert n >= 3
+    rng = np.random.default_rng(4)
+    for m in (0, n // 2):                                                    # garble two payloads, keep the framing
+        o, l = int(tab["comp_off"][m]), int(tab["comp_len"][m])
+        raw[o + 20:o + l] = bytes(rng.integers(0, 256, size=l - 20, dtype=np.uint8))
+    out, bad, status = ctx.inflate_bgzf(bytes(raw), return_status=True)
+    st = status.cpu().numpy()
+    assert bad >= 1 and set(np.flatnonzero(st)) <= {0, n // 2}
+    # the untouched members are still right
+    off = np.concatenate([[0], np.cumsum(tab["isize"])]).astype(np.int64)
+    got = out.cpu().numpy().tobytes()
+    for m in range(n):
+        if st[m] == 0 and m not in (0, n // 2):
+            assert got[off[m]:off[m + 1]] == text[off[m]:off[m + 1]]
