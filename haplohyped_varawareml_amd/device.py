@@ -236,6 +236,17 @@ class Context:
                                                 _stream()))
         return (dst, int(bad.value), status) if return_status else (dst, int(bad.value))
 
+    def inflate_members(self, d_src, src_bytes, d_comp_off, d_comp_len, d_out_off, d_isize, n, dst, dst_bytes, status,
+                        count_bad=True):
+        """`hhgt_inflate_members` on device tensors (see include/hhgt.h) -> number of members flagged in `status`
+        (count_bad=False: launch only, no synchronisation, returns None — look at `status` later)"""
+        bad = C.c_uint64(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_inflate_members(self.h, _ptr(d_src), int(src_bytes), _ptr(d_comp_off), _ptr(d_comp_len),
+                                                _ptr(d_out_off), _ptr(d_isize), int(n), _ptr(dst), int(dst_bytes),
+                                                _ptr(status), C.byref(bad) if count_bad else None, _stream()))
+        return int(bad.value) if count_bad else None
+
     # ---- synthetic workloads (bench / test tooling) -----------------------------------------------
     def synth_fixed(self, contig, table, n_samples, seed, v_first=0, with_header=True, names=None):
         """Render a fixed-width synthetic shard directly in HBM.  -> (text uint8 tensor, nbytes)"""

@@ -5,6 +5,7 @@ columns -> completed columns go through hhgt_compress_chunks and leave the devic
 Replaces the body of VCFtoHDF5Converter.genotype_vcf_to_hdf5
 (/root/reference/src/haplohyped/vcf_to_h5.py:79-140): one pass per FILE for all samples instead of one
 pass per (donor, chromosome)."""
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -13,6 +14,12 @@ import torch
 
 from . import device as dev
 from .reader import VcfReader, parse_header
+
+
+def _is_bgzf_file(path):
+    with open(path, "rb") as f:
+        h = f.read(18)
+    return len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:16] == b"BC\x02\x00"
 
 
 @dataclass
@@ -40,21 +47,174 @@ def _accumulate(fs, st):
         setattr(fs, k, getattr(fs, k) + st[k])
 
 
+class _HostBlocks:
+    """Text blocks from the C++ reader (host inflate / pread threads -> pinned ring -> hipMemcpyAsync)."""
+
+    def __init__(self, ctx, path, block_bytes, n_threads):
+        self.rd = VcfReader(path, block_bytes=block_bytes, n_threads=n_threads)
+        self.is_bgzf = self.rd.is_bgzf
+        self._blk = None
+
+    def first(self, dbuf, copy_stream):
+        blk = self.rd.next_block()
+        if blk is None:
+            return None, 0
+        self.rd.copy_async(blk, dbuf.data_ptr(), copy_stream.cuda_stream)
+        copy_stream.synchronize()
+        return blk, blk.size
+
+    def start_next(self, dbuf, prev, prev_n, copy_stream):
+        self._blk = self.rd.next_block()
+        if self._blk is not None:
+            self.rd.copy_async(self._blk, dbuf.data_ptr(), copy_stream.cuda_stream)   # overlaps the kernels of the caller
+
+    def finish_next(self, dbuf, copy_stream):
+        copy_stream.synchronize()   # the block sits in HBM before its pinned source is recycled
+        return self._blk.size if self._blk is not None else 0
+
+    def file_bytes(self):
+        return self.rd.stats()["file_bytes"]
+
+    def close(self):
+        self.rd.close()
+
+
+class _DeviceBgzfBlocks:
+    """Text blocks of a BGZF file inflated on the device: the host walks the member headers of the
+    memory-mapped file, the compressed members of one block cross PCIe as they are, `hhgt_inflate_members` writes
+    their text behind the partial last line carried over from the previous block.  A block handed to the caller
+    ends with a newline (except the last one of the file)."""
+    is_bgzf = True
+
+    def __init__(self, ctx, path, block_bytes):
+        self.ctx = ctx
+        self.raw = np.memmap(path, dtype=np.uint8, mode="r")
+        tab = dev.bgzf_scan(self.raw)
+        if tab["consumed"] != self.raw.size:
+            raise dev.HhgtError(-4, f"{path}: {self.raw.size - tab['consumed']} bytes behind the last whole BGZF member")
+        self.off, self.len, self.isz = tab["comp_off"], tab["comp_len"], tab["isize"]
+        self.block_bytes = block_bytes
+        self.m = 0                      # next member
+        self._pending = None
+        # members per block: inflated sizes are known, keep one maximal line of slack for the carry
+        self.room = block_bytes - (4 << 20)
+        if self.room < (1 << 20):
+            raise dev.HhgtError(-1, "device BGZF inflate needs block_bytes of at least 5 MiB")
+
+    def _inflate_into(self, dbuf, carry):
+        """members [m, m1) -> dbuf[carry:], returns bytes in dbuf; the stream is the current torch stream"""
+        isz = self.isz
+        m0, total = self.m, 0
+        m1 = m0
+        while m1 < len(isz) and total + int(isz[m1]) <= self.room - carry:
+            total += int(isz[m1])
+            m1 += 1
+        if m1 == m0 and m0 < len(isz):
+            raise dev.HhgtError(-4, "a line longer than the text block: raise block_bytes")
+        self.m = m1
+        if m1 == m0:
+            return carry
+        a = int(self.off[m0])
+        b = int(self.off[m1 - 1]) + int(self.len[m1 - 1])
+        d = self.ctx.device
+        padded = np.zeros((b - a + 3) // 4 * 4 + 4, dtype=np.uint8)
+        padded[:b - a] = self.raw[a:b]
+        out_off = np.zeros(m1 - m0, dtype=np.uint64)
+        np.cumsum(isz[m0:m1 - 1], dtype=np.uint64, out=out_off[1:])
+        out_off += np.uint64(carry)
+        d_src = torch.from_numpy(padded).to(d, non_blocking=True)
+        d_off = torch.from_numpy(self.off[m0:m1] - np.uint64(a)).to(d, non_blocking=True)
+        d_len = torch.from_numpy(np.ascontiguousarray(self.len[m0:m1])).to(d, non_blocking=True)
+        d_out = torch.from_numpy(out_off).to(d, non_blocking=True)
+        d_isz = torch.from_numpy(np.ascontiguousarray(isz[m0:m1])).to(d, non_blocking=True)
+        status = torch.zeros(m1 - m0, dtype=torch.int32, device=d)
+        self.ctx.inflate_members(d_src, padded.size, d_off, d_len, d_out, d_isz, m1 - m0, dbuf, carry + total, status,
+                                 count_bad=False)   # no host wait here: the caller's kernels are launched next
+        self._pending = (status, m0)
+        return carry + total
+
+    def _check(self):
+        """raises if a member of the last launch failed (synchronises the inflate stream)"""
+        if self._pending is not None:
+            status, m0 = self._pending
+            self._pending = None
+            nz = torch.nonzero(status)
+            if nz.numel():
+                k = int(nz[0])
+                raise dev.HhgtError(-7, f"BGZF member {m0 + k}: DEFLATE stream is corrupt (status {int(status[k])})")
+
+    def _cut(self, dbuf, n):
+        """bytes of dbuf[:n] that are whole lines (everything at end of file)"""
+        if self.m >= len(self.isz) or n == 0:
+            return n
+        lo = max(0, n - (4 << 20))
+        nl = torch.nonzero(dbuf[lo:n] == 10)
+        if nl.numel() == 0:
+            raise dev.HhgtError(-4, "a line longer than 4 MiB")
+        return lo + int(nl[-1]) + 1
+
+    def first(self, dbuf, copy_stream):
+        with torch.cuda.stream(copy_stream):
+            n = self._inflate_into(dbuf, 0)
+            self._check()
+            cut = self._cut(dbuf, n)
+            head = dbuf[:min(cut, 8 << 20)].cpu().numpy()
+        copy_stream.synchronize()
+        self._tail = (n, cut)
+        return (head if cut else None), cut
+
+    def start_next(self, dbuf, prev, prev_n, copy_stream):
+        n, cut = self._tail
+        with torch.cuda.stream(copy_stream):
+            carry = n - cut
+            if carry:
+                dbuf[:carry].copy_(prev[cut:n])
+            n2 = self._inflate_into(dbuf, carry)
+        self._tail = (n2, None)
+
+    def finish_next(self, dbuf, copy_stream):
+        with torch.cuda.stream(copy_stream):
+            self._check()
+            n2 = self._tail[0]
+            cut2 = self._cut(dbuf, n2)
+        copy_stream.synchronize()
+        self._tail = (n2, cut2)
+        return cut2
+
+    def file_bytes(self):
+        return int(self.raw.size)
+
+    def close(self):
+        self.raw = None
+
+
 def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=64 << 20, n_threads=0,
-                sites_only=False, on_columns=None, on_variants=None, on_header=None, compress=True, fmt=dev.BLOSC2):
+                sites_only=False, on_columns=None, on_variants=None, on_header=None, compress=True, fmt=dev.BLOSC2,
+                device_inflate=None):
     """Streams one VCF through the device path.
     on_header(samples)                         once
     on_variants(start, ref, alt)               numpy arrays for each text block's kept records
     on_columns(G_cols, n_cols, framed)         for every batch of completed chunk columns:
         G_cols: uint8 CUDA tensor [n_cols * column_bytes] (valid during the call),
         framed: (host bytes, offsets uint64[n_chunks+1]) when compress=True else None
+    device_inflate: BGZF members are inflated on the device instead of by the host reader threads (None: the
+        HHGT_DEVICE_INFLATE environment variable, default off — the north star keeps BGZF on the host)
     -> FileStats"""
     t_start = time.perf_counter()
     fs = FileStats()
     d = ctx.device
-    with VcfReader(path, block_bytes=block_bytes, n_threads=n_threads) as rd:
+    if device_inflate is None:
+        device_inflate = os.environ.get("HHGT_DEVICE_INFLATE", "0") not in ("", "0")
+    if device_inflate and _is_bgzf_file(path):
+        rd = _DeviceBgzfBlocks(ctx, path, block_bytes)
+    else:
+        rd = _HostBlocks(ctx, path, block_bytes, n_threads)
+    try:
         fs.is_bgzf = rd.is_bgzf
-        blk = rd.next_block()
+        dbuf = [torch.empty(block_bytes + 64, dtype=torch.uint8, device=d) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=d)
+        main = torch.cuda.current_stream(d)
+        blk, blk_n = rd.first(dbuf[0], copy_stream)
         if blk is None:
             raise dev.HhgtError(-4, f"{path}: empty file (no VCF header)")
         names, _ = parse_header(blk)
@@ -78,17 +238,10 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
                                     torch.zeros(cap, dtype=torch.uint8, device=d), 0, {})
 
         stage, spare = new_stage(), new_stage()
-        dbuf = [torch.empty(block_bytes + 64, dtype=torch.uint8, device=d) for _ in range(2)]
-        copy_stream = torch.cuda.Stream(device=d)
-        main = torch.cuda.current_stream(d)
-        rd.copy_async(blk, dbuf[0].data_ptr(), copy_stream.cuda_stream)
-        copy_stream.synchronize()
-        cur_n, i, fill, v_global = blk.size, 0, 0, 0
+        cur_n, i, fill, v_global = blk_n, 0, 0, 0
         last_run = None
         while cur_n:
-            nxt = rd.next_block()
-            if nxt is not None:
-                rd.copy_async(nxt, dbuf[1 - i].data_ptr(), copy_stream.cuda_stream)   # overlaps the kernels below
+            rd.start_next(dbuf[1 - i], dbuf[i], cur_n, copy_stream)   # overlaps the kernels below
             ctx.encode_text(dbuf[i][:cur_n], S, region=region, v_base=fill, out=stage)
             st = stage.stats
             _accumulate(fs, st)
@@ -113,9 +266,9 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
                 stage, spare = spare, stage
             fill = rem
             v_global += k
-            copy_stream.synchronize()   # the next block sits in HBM before its pinned source is recycled
+            nxt_n = rd.finish_next(dbuf[1 - i], copy_stream)
             main.synchronize()
-            cur_n = nxt.size if nxt is not None else 0
+            cur_n = nxt_n
             i ^= 1
         if fill and S:
             stage.n_kept = fill
@@ -124,7 +277,9 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
         elif S:
             pass
         fs.n_kept = v_global
-        fs.file_bytes = rd.stats()["file_bytes"]
+        fs.file_bytes = rd.file_bytes()
+    finally:
+        rd.close()
     fs.seconds = time.perf_counter() - t_start
     return fs
 

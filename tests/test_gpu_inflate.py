@@ -112,3 +112,24 @@ def test_corrupt_members_are_flagged(ctx):
     for m in range(n):
         if st[m] == 0 and m not in (0, n // 2):
             assert got[off[m]:off[m + 1]] == text[off[m]:off[m + 1]]
+
+
+def test_stream_file_device_inflate_matches_host_inflate(ctx, tmp_path):
+    """the converter's streaming path with BGZF inflated on the device == the same file through the host reader
+    (several text blocks, lines carried across block and member boundaries)"""
+    from haplohyped_varawareml_amd import pipeline
+    S = 300
+    tab = synth.variant_table(21, 9000, S)
+    text_dev, _ = ctx.synth_fixed("chr1", tab, S, seed=21)
+    path = tmp_path / "c.vcf.gz"
+    write_bgzf(str(path), text_dev.cpu().numpy().tobytes())
+    res = {}
+    for mode in (False, True):
+        cols, tabs = [], []
+        fs = pipeline.stream_file(ctx, str(path), sc=64, vc=512, block_bytes=6 << 20, compress=False, device_inflate=mode,
+                                  on_columns=lambda G, n, framed: cols.append(G.cpu().numpy().copy()),
+                                  on_variants=lambda st, r, a: tabs.append((st.copy(), r.copy(), a.copy())))
+        res[mode] = (fs, np.concatenate(cols), np.concatenate([t[0] for t in tabs]))
+    (fh, Gh, sh), (fd, Gd, sd) = res[False], res[True]
+    assert fd.is_bgzf and fd.n_kept == fh.n_kept == 9000 and fd.n_lines == fh.n_lines and fd.text_bytes == fh.text_bytes
+    assert np.array_equal(Gh, Gd) and np.array_equal(sh, sd)
