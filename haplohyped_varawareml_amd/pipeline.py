@@ -37,6 +37,10 @@ class FileStats:
     raw_bytes: int = 0
     compressed_bytes: int = 0
     seconds: float = 0.0
+    t_setup: float = 0.0      # host seconds: open, first block, buffers
+    t_source: float = 0.0     # host seconds inside the block source (launch / wait for the next text block)
+    t_encode: float = 0.0     # host seconds inside hhgt_encode_text (synchronises)
+    t_emit: float = 0.0       # host seconds compressing + handing out completed columns
     is_bgzf: bool = False
     samples: list = field(default_factory=list)
     chrom_runs: list = field(default_factory=list)
@@ -93,6 +97,8 @@ class _DeviceBgzfBlocks:
         if tab["consumed"] != self.raw.size:
             raise dev.HhgtError(-4, f"{path}: {self.raw.size - tab['consumed']} bytes behind the last whole BGZF member")
         self.off, self.len, self.isz = tab["comp_off"], tab["comp_len"], tab["isize"]
+        if block_bytes is None:
+            block_bytes = min(1 << 30, (int(self.isz.sum(dtype=np.uint64)) + (9 << 20)) // (1 << 20) * (1 << 20))
         self.block_bytes = block_bytes
         self.m = 0                      # next member
         self._pending = None
@@ -188,7 +194,7 @@ class _DeviceBgzfBlocks:
         self.raw = None
 
 
-def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=64 << 20, n_threads=0,
+def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=None, n_threads=0,
                 sites_only=False, on_columns=None, on_variants=None, on_header=None, compress=True, fmt=dev.BLOSC2,
                 device_inflate=None):
     """Streams one VCF through the device path.
@@ -206,8 +212,13 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
     if device_inflate is None:
         device_inflate = os.environ.get("HHGT_DEVICE_INFLATE", "0") not in ("", "0")
     if device_inflate and _is_bgzf_file(path):
+        # one wave per member: a launch wants >= 10 k members (64 KiB of text each) to fill the chip, so the text
+        # block is 1 GiB unless the file is smaller (measured: 64 MiB blocks 1.4 M variants/s, 1 GiB 4.0 M)
         rd = _DeviceBgzfBlocks(ctx, path, block_bytes)
+        block_bytes = rd.block_bytes
     else:
+        if block_bytes is None:
+            block_bytes = 64 << 20
         rd = _HostBlocks(ctx, path, block_bytes, n_threads)
     try:
         fs.is_bgzf = rd.is_bgzf
@@ -238,11 +249,17 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
                                     torch.zeros(cap, dtype=torch.uint8, device=d), 0, {})
 
         stage, spare = new_stage(), new_stage()
+        fs.t_setup = time.perf_counter() - t_start
         cur_n, i, fill, v_global = blk_n, 0, 0, 0
         last_run = None
         while cur_n:
+            t0 = time.perf_counter()
             rd.start_next(dbuf[1 - i], dbuf[i], cur_n, copy_stream)   # overlaps the kernels below
+            t1 = time.perf_counter()
             ctx.encode_text(dbuf[i][:cur_n], S, region=region, v_base=fill, out=stage)
+            t2 = time.perf_counter()
+            fs.t_source += t1 - t0
+            fs.t_encode += t2 - t1
             st = stage.stats
             _accumulate(fs, st)
             fs.text_bytes += cur_n
@@ -257,7 +274,9 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
             total = fill + k
             done = total // vc
             if done and S:
+                t0 = time.perf_counter()
                 _emit(ctx, stage, done, col_bytes, chunk_nbytes, on_columns, compress, fmt, fs)
+                fs.t_emit += time.perf_counter() - t0
             rem = total - done * vc
             if done:
                 # carry the partial column into column 0 of the other staging window
@@ -266,7 +285,9 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
                 stage, spare = spare, stage
             fill = rem
             v_global += k
+            t0 = time.perf_counter()
             nxt_n = rd.finish_next(dbuf[1 - i], copy_stream)
+            fs.t_source += time.perf_counter() - t0
             main.synchronize()
             cur_n = nxt_n
             i ^= 1

@@ -20,8 +20,10 @@ def main():
     ap.add_argument("--samples", type=int, default=2504)
     ap.add_argument("--kind", choices=["bgzf", "gzip", "plain"], default="bgzf")
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--block-mb", type=int, default=64)
+    ap.add_argument("--block-mb", type=int, default=0, help="text block size (0: the pipeline default)")
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--device-inflate", action="store_true", help="BGZF members inflated on the device (f-4)")
+    ap.add_argument("--level", type=int, default=1, help="zlib level of the synthetic BGZF / gzip file")
     a = ap.parse_args()
     import torch  # noqa: F401
     from haplohyped_varawareml_amd import device as dev, synth
@@ -36,9 +38,9 @@ def main():
     p = os.path.join(d, "chr22.filtered.vcf.gz")
     t0 = time.time()
     if a.kind == "bgzf":
-        write_bgzf(p, text, level=1)
+        write_bgzf(p, text, level=a.level)
     elif a.kind == "gzip":
-        with gzip.open(p, "wb", compresslevel=1) as f:
+        with gzip.open(p, "wb", compresslevel=a.level) as f:
             f.write(text)
     else:
         open(p, "wb").write(text)
@@ -46,13 +48,14 @@ def main():
     best = None
     for _ in range(a.repeat):
         sink = []
-        fs = stream_file(ctx, p, region="chr22", block_bytes=a.block_mb << 20, n_threads=a.threads,
+        fs = stream_file(ctx, p, region="chr22", block_bytes=(a.block_mb << 20) or None, n_threads=a.threads, device_inflate=a.device_inflate,
                          on_columns=lambda G, n, framed: sink.append(framed[0].size))
         if best is None or fs.seconds < best.seconds:
             best = fs
-    out = dict(kind=a.kind, variants=a.variants, samples=a.samples, text_bytes=best.text_bytes,
+    out = dict(kind=a.kind, device_inflate=bool(a.device_inflate and a.kind == 'bgzf'), level=a.level, variants=a.variants, samples=a.samples, text_bytes=best.text_bytes,
                file_bytes=os.path.getsize(p), seconds=best.seconds, variants_per_s=best.n_kept / best.seconds,
                text_GBps=best.text_bytes / best.seconds / 1e9, ratio=best.raw_bytes / max(best.compressed_bytes, 1),
+               t_setup=best.t_setup, t_source=best.t_source, t_encode=best.t_encode, t_emit=best.t_emit,
                host_cores=os.cpu_count(), threads=a.threads or os.cpu_count(), prep_seconds=prep)
     print(json.dumps(out))
     os.remove(p)
