@@ -133,3 +133,33 @@ def test_stream_file_device_inflate_matches_host_inflate(ctx, tmp_path):
     (fh, Gh, sh), (fd, Gd, sd) = res[False], res[True]
     assert fd.is_bgzf and fd.n_kept == fh.n_kept == 9000 and fd.n_lines == fh.n_lines and fd.text_bytes == fh.text_bytes
     assert np.array_equal(Gh, Gd) and np.array_equal(sh, sd)
+
+
+def test_fuzzed_members_terminate_and_stay_in_bounds(ctx):
+    """400 members, each garbled differently (bit flips, random runs, truncated tables): every wave must finish, flag or
+    decode its member, and never write outside the member's slice (guard bytes around the output stay intact)."""
+    rng = np.random.default_rng(2024)
+    chunks = [vcf_like(12, 100 + (i % 7) * 30, 100 + i) for i in range(400)]
+    raw = bytearray(bgzf(chunks, 6))
+    tab = dev.bgzf_scan(bytes(raw))
+    n = len(tab["isize"])
+    touched = set()
+    for m in range(0, n, 2):
+        o, l = int(tab["comp_off"][m]), int(tab["comp_len"][m])
+        kind = m % 6
+        if kind == 0:
+            for _ in range(3):
+                raw[o + int(rng.integers(0, l))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:
+            a = int(rng.integers(0, l - 4))
+            raw[o + a:o + l] = bytes(rng.integers(0, 256, size=l - a, dtype=np.uint8))
+        else:
+            raw[o:o + 12] = bytes(rng.integers(0, 256, size=12, dtype=np.uint8))      # block header + code tables
+        touched.add(m)
+    out, bad, status = ctx.inflate_bgzf(bytes(raw), return_status=True)
+    st = status.cpu().numpy()
+    assert set(np.flatnonzero(st).tolist()) <= touched and bad == int((st != 0).sum()) and bad > len(touched) // 2
+    got = out.cpu().numpy().tobytes()
+    off = np.concatenate([[0], np.cumsum(tab["isize"])]).astype(np.int64)
+    for m in range(1, n, 2):                                                        # neighbours of garbled members
+        assert got[off[m]:off[m + 1]] == chunks[m], m
