@@ -9,8 +9,8 @@
 //     length L (`code - first[L] < count[L]`), one ballot picks the length, one readlane the symbol index;
 //   * table construction (counts, first codes, symbols sorted by code) is ballots over 64 code lengths at a time;
 //   * match copies move 64 bytes per step (matches of VCF genotype text are long: "0|0\t" x 64);
-//   * the compressed input is read 256 bytes at a time (one dword per lane, double-buffered) and handed to the
-//     bit buffer by readlane, so the symbol loop never waits on a dependent global load.
+//   * the compressed input reaches the bit buffer through scalar loads (read-only data, uniform address), one dword
+//     ahead, so a refill never waits behind the byte stores of earlier symbols (vector loads share vmcnt with them).
 // The output window is the member's slice of the destination itself (deflate distances never leave the member).
 // CRC32 of the members is not checked here; ISIZE and the bit budget of each member are.
 #include "common.h"
@@ -133,33 +133,28 @@ __global__ __launch_bounds__(256) void k_inflate_members(const uint8_t *__restri
     const uint32_t end_word = (uint32_t)((p0 + clen + 3u) >> 2);  // first dword wholly behind the member's payload
     const uint32_t shiftv = (lane >= 1u && lane <= 15u) ? 32u - lane : 31u;
 
-    // ---- compressed input: dwords [wb, wb + 64) in vin, the next 64 in vnext ----
-    uint32_t wb = (uint32_t)(p0 >> 2), wi = wb;  // dword indices into src (the launcher keeps src_bytes below 16 GiB)
-    auto load_win = [&](uint32_t base) {
-        const uint32_t w = base + lane;
-        return srcw[w < last_word ? w : last_word];
+    // ---- compressed input: one dword ahead of the bit buffer, fetched with scalar loads (the payload is read-only
+    // for the kernel, the address is wave-uniform).  Scalar loads count in lgkmcnt: a refill never waits for the
+    // byte stores of earlier symbols, which a vector-load window (vmcnt) did at every refill.
+    uint32_t wi = (uint32_t)(p0 >> 2);  // dword index into src (the launcher keeps src_bytes below 16 GiB)
+    uint32_t ahead = 0;
+    auto sload = [&](uint32_t w) -> uint32_t {
+        const uint32_t *q = srcw + (w < last_word ? w : last_word);
+        uint32_t v;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q) : "memory");
+        return v;
     };
-    uint32_t vin = load_win(wb), vnext = load_win(wb + 64u);
-    auto fetch = [&]() -> uint32_t {  // dword wi, then wi += 1
-        uint32_t rel = wi - wb;
-        if (rel >= 64u) {
-            if (rel < 128u) {
-                vin = vnext;
-                wb += 64u;
-            } else {
-                wb = wi;
-                vin = load_win(wb);
-            }
-            vnext = load_win(wb + 64u);
-            rel = wi - wb;
-        }
+    auto fetch = [&]() -> uint32_t {  // dword wi, then wi += 1; the dword after it is requested for the next call
+        const uint32_t v = ahead;
         ++wi;
-        return (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)rel);
+        ahead = sload(wi);
+        return v;
     };
     uint64_t bb;
     uint32_t bc;
     auto start_at = [&](uint64_t byte_pos) {
         wi = (uint32_t)(byte_pos >> 2);
+        ahead = sload(wi);
         const uint32_t mis = (uint32_t)byte_pos & 3u;
         bb = (uint64_t)(fetch() >> (8u * mis));
         bc = 32u - 8u * mis;
