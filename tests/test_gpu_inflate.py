@@ -163,3 +163,25 @@ def test_fuzzed_members_terminate_and_stay_in_bounds(ctx):
     off = np.concatenate([[0], np.cumsum(tab["isize"])]).astype(np.int64)
     for m in range(1, n, 2):                                                        # neighbours of garbled members
         assert got[off[m]:off[m + 1]] == chunks[m], m
+
+
+def test_converter_with_device_inflate_writes_the_same_h5(ctx, tmp_path, golden_dir, monkeypatch):
+    """vcf_to_h5 with HHGT_DEVICE_INFLATE=1: BGZF shards go through the device inflater, the plain-gzip fixture keeps the
+    host reader; the cohort file is byte-identical to the one written with the host inflater"""
+    import os
+    import shutil
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr22.filtered.vcf.gz"), vcf_dir / "chr22.filtered.vcf.gz")
+    names = [l.strip() for l in open(os.path.join(golden_dir, "ipscs_samples_test.txt")) if l.strip()]
+    write_bgzf(str(vcf_dir / "chr4.filtered.vcf.gz"), synth.render_mixed("chr4", 5000, len(names), seed=4, names=names))
+    files = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HHGT_DEVICE_INFLATE", mode)
+        conv = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / f"out{mode}"),
+                                  os.path.join(golden_dir, "ipscs_samples_test.txt"), cores=2, cxx_threads=1)
+        conv.run()
+        assert conv.stats["chr_4"].is_bgzf and conv.stats["chr_4"].n_kept > 1000
+        files[mode] = open(conv.h5_path, "rb").read()
+    assert files["0"] == files["1"]
