@@ -79,8 +79,8 @@ def load():
     L.hhgt_compress_bound.argtypes = [u64, u64, i32, i32]
     L.hhgt_compress_chunks.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, u64, vp, C.POINTER(u64), vp]
     L.hhgt_decompress_chunks.argtypes = [vp, vp, vp, u64, u64, i32, i32, vp, C.POINTER(u64), vp]
-    L.hhgt_bgzf_scan.argtypes = [vp, u64, u64, vp, vp, vp, C.POINTER(u64), C.POINTER(u64)]
-    L.hhgt_inflate_members.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, vp, u64, vp, C.POINTER(u64), vp]
+    L.hhgt_bgzf_scan.argtypes = [vp, u64, u64, vp, vp, vp, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.hhgt_inflate_members.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, vp, u64, vp, vp, C.POINTER(u64), vp]
     L.hhgt_onehot_windows.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, i32, vp, vp, vp]
     L.hhgt_onehot_bases_u8.argtypes = [vp, vp, u64, vp, i32, vp, vp]
     L.hhgt_profile_enable.argtypes = [vp, i32]

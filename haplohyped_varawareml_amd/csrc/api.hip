@@ -92,7 +92,7 @@ extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
                       &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff,
                       &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_off,
                       &c->counters, &c->region, &c->lz_scratch, &c->lz_csize, &c->fr_bsize, &c->fr_csize,
-                      &c->fr_flags, &c->dec_bad, &c->oh_ovl, &c->oh_lut};
+                      &c->fr_flags, &c->dec_bad, &c->oh_ovl, &c->oh_lut, &c->crc_x2n};
     for (DevBuf *b : bufs) b->release();
     if (c->h_counters) hipHostFree(c->h_counters);
     for (auto &p : c->pending) {
@@ -562,8 +562,8 @@ __global__ void k_count_nonzero_u32(const uint32_t *__restrict__ v, uint64_t n, 
 
 extern "C" int hhgt_inflate_members(hhgt_ctx *c, const void *d_src, uint64_t src_bytes, const uint64_t *d_comp_off,
                                     const uint32_t *d_comp_len, const uint64_t *d_out_off, const uint32_t *d_isize,
-                                    uint64_t n_members, void *d_dst, uint64_t dst_bytes, uint32_t *d_status,
-                                    uint64_t *n_bad, void *stream)
+                                    uint64_t n_members, void *d_dst, uint64_t dst_bytes, const uint32_t *d_crc32,
+                                    uint32_t *d_status, uint64_t *n_bad, void *stream)
 {
     if (!c || !d_src || !d_comp_off || !d_comp_len || !d_out_off || !d_isize || !d_status || (!d_dst && dst_bytes))
         return HHGT_ERR_ARG;
@@ -571,10 +571,18 @@ extern "C" int hhgt_inflate_members(hhgt_ctx *c, const void *d_src, uint64_t src
     HIP_TRY(hipSetDevice(c->device));
     if (n_bad) *n_bad = 0;
     if (n_members == 0) return HHGT_OK;
+    if (d_crc32 && !c->crc_x2n_ready) {
+        uint32_t t[32];
+        crc32_x2n_table(t);
+        TRY(c->crc_x2n.ensure(sizeof(t)));
+        HIP_TRY(hipMemcpy(c->crc_x2n.p, t, sizeof(t), hipMemcpyHostToDevice));
+        c->crc_x2n_ready = true;
+    }
     {
         StageTimer t(c, st, HHGT_STAGE_INFLATE);
         TRY(launch_inflate(static_cast<const uint8_t *>(d_src), src_bytes, d_comp_off, d_comp_len, d_out_off, d_isize,
-                           n_members, static_cast<uint8_t *>(d_dst), dst_bytes, d_status, st));
+                           n_members, static_cast<uint8_t *>(d_dst), dst_bytes, d_status, d_crc32,
+                           c->crc_x2n.as<uint32_t>(), st));
         t.stop();
     }
     if (n_bad) {

@@ -90,7 +90,8 @@ struct hhgt_ctx {
     DevBuf counters;       // DevCounters
     DevBuf region;         // RegionFilter
     // compress workspaces
-    DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut;
+    DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut, crc_x2n;
+    bool crc_x2n_ready = false;
     // pinned host mirror for counters
     DevCounters *h_counters = nullptr;
     // last encode's chrom runs (host)
@@ -163,7 +164,8 @@ int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_
                   int typesize, int blocksize, uint8_t *d_dst, unsigned long long *d_bad, hipStream_t st);
 int launch_inflate(const uint8_t *d_src, uint64_t src_bytes, const uint64_t *d_comp_off, const uint32_t *d_comp_len,
                    const uint64_t *d_out_off, const uint32_t *d_isize, uint64_t n_members, uint8_t *d_dst,
-                   uint64_t dst_bytes, uint32_t *d_status, hipStream_t st);
+                   uint64_t dst_bytes, uint32_t *d_status, const uint32_t *d_crc32, const uint32_t *d_x2n, hipStream_t st);
+void crc32_x2n_table(uint32_t *t /*[32]*/);
 
 // layout helper shared by host and device
 static inline __host__ __device__ uint64_t layout_offset(const LayoutDev &L, uint32_t s, uint64_t v)

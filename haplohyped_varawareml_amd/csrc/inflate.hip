@@ -12,7 +12,7 @@
 //   * the compressed input reaches the bit buffer through scalar loads (read-only data, uniform address), one dword
 //     ahead, so a refill never waits behind the byte stores of earlier symbols (vector loads share vmcnt with them).
 // The output window is the member's slice of the destination itself (deflate distances never leave the member).
-// CRC32 of the members is not checked here; ISIZE and the bit budget of each member are.
+// ISIZE and the bit budget of each member are checked by the inflate kernel, the CRC-32 of its text by a second one.
 #include "common.h"
 
 namespace {
@@ -92,6 +92,7 @@ enum : uint32_t {
     INF_OUTPUT_OVERRUN = 6,
     INF_INPUT_OVERRUN = 7,
     INF_SIZE_MISMATCH = 8,
+    INF_CRC_MISMATCH = 9,
 };
 
 // order in which the code-length code lengths are stored (RFC 1951 3.2.7), 5 bits each, packed
@@ -388,9 +389,103 @@ __global__ __launch_bounds__(256) void k_inflate_members(const uint8_t *__restri
     if (lane == 0u) status[mem] = err;
 }
 
+// ---- CRC-32 of the inflated members (RFC 1952 trailer; htslib's bgzf.c rejects a member whose CRC differs) ----
+// One wave per member again, coalesced (see k_crc32_members); the GF(2) arithmetic is zlib's crc32_combine
+// (multmodp / x2nmodp, reflected polynomial 0xEDB88320).
+namespace {
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+
+__host__ __device__ inline uint32_t crc_multmodp(uint32_t a, uint32_t b)  // a(x) * b(x) mod P, reflected bit order
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & (0x80000000u >> i)) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+}  // namespace
+
+// x2n[k] = x^(2^k) mod P.  grid = ceil(n_members / 4), block = 256.
+// The text is walked in tiles of 4 KiB: the wave loads a tile with coalesced dwords into LDS (17-dword rows, so
+// that the 64-byte pieces the lanes then read are bank-conflict free), lane i runs the bytewise table CRC over piece i
+// of the tile.  CRC is linear over GF(2): with s_i the raw CRC (init 0) of "the message with every byte outside lane
+// i's pieces zeroed", raw(M) = XOR_i s_i.  Between two pieces of a lane lie 4032 zero bytes = one multiplication by
+// x^(8 * 4032); behind its last byte lie (n - end_i) zero bytes = one multiplication by x^(8 (n - end_i)).  Finally
+// crc32(M) = ~(raw(M) ^ 0xFFFFFFFF * x^(8 n)).
+__global__ __launch_bounds__(256) void k_crc32_members(const uint8_t *__restrict__ text,
+                                                       const unsigned long long *__restrict__ out_off,
+                                                       const uint32_t *__restrict__ isize,
+                                                       const uint32_t *__restrict__ want, uint32_t n_members,
+                                                       const uint32_t *__restrict__ x2n, uint32_t *status)
+{
+    __shared__ uint32_t s_tab[256];
+    __shared__ uint32_t s_x2n[32];
+    __shared__ uint32_t s_tile[4][64 * 17];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        s_tab[threadIdx.x] = c;
+        if (threadIdx.x < 32u) s_x2n[threadIdx.x] = x2n[threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t mem = blockIdx.x * 4u + wave;
+    if (mem >= n_members) return;  // (no barrier below)
+    if (status[mem] != 0u) return;  // not inflated: nothing to check
+    const uint32_t n = isize[mem];
+    const uint8_t *p = text + out_off[mem];
+    uint32_t *tile = s_tile[wave];
+    auto x_pow_bytes = [&](uint32_t nbytes) {  // x^(8 * nbytes) mod P
+        uint32_t f = 0x80000000u;              // x^0
+        for (uint32_t k = 0; k < 17u; ++k)
+            if ((nbytes >> k) & 1u) f = crc_multmodp(s_x2n[k + 3u], f);
+        return f;
+    };
+    const uint32_t gap = x_pow_bytes(4032u);
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    uint32_t s = 0, end = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 4096u) {
+        const uint32_t tn = n - t0 < 4096u ? n - t0 : 4096u;  // bytes of this tile
+        // tile -> LDS: dword g of the tile (g = 64 j + lane) lands in row g / 16, column g % 16
+        if (tn == 4096u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                const uint32_t g = 64u * j + lane;
+                tile[(g >> 4) * 17u + (g & 15u)] = *reinterpret_cast<const u32u *>(p + t0 + 4u * g);
+            }
+        } else {
+            for (uint32_t j = 0; j < 16u; ++j) {
+                const uint32_t g = 64u * j + lane, o = 4u * g;
+                uint32_t w = 0;
+                if (o + 4u <= tn) w = *reinterpret_cast<const u32u *>(p + t0 + o);
+                else
+                    for (uint32_t k = 0; o + k < tn; ++k) w |= (uint32_t)p[t0 + o + k] << (8u * k);
+                tile[(g >> 4) * 17u + (g & 15u)] = w;
+            }
+        }
+        // piece of this lane: bytes [64 lane, 64 lane + 64) of the tile, cut at tn
+        const uint32_t lo = 64u * lane;
+        if (lo < tn) {
+            const uint32_t m = tn - lo < 64u ? tn - lo : 64u;
+            s = crc_multmodp(gap, s);  // the 4032 zero bytes since this lane's previous piece (s = 0 before the first)
+            const uint32_t *row = tile + lane * 17u;
+            for (uint32_t k = 0; k < m; ++k) {
+                const uint32_t b = (row[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
+                s = s_tab[(s ^ b) & 0xFFu] ^ (s >> 8);
+            }
+            end = t0 + lo + m;
+        }
+    }
+    uint32_t v = s ? crc_multmodp(x_pow_bytes(n - end), s) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) v ^= (uint32_t)__shfl_xor((int)v, d, 64);
+    const uint32_t crc = ~(v ^ crc_multmodp(x_pow_bytes(n), 0xFFFFFFFFu));
+    if (lane == 0u && crc != want[mem]) status[mem] = 9u;  // INF_CRC_MISMATCH
+}
+
 int launch_inflate(const uint8_t *d_src, uint64_t src_bytes, const uint64_t *d_comp_off, const uint32_t *d_comp_len,
                    const uint64_t *d_out_off, const uint32_t *d_isize, uint64_t n_members, uint8_t *d_dst,
-                   uint64_t dst_bytes, uint32_t *d_status, hipStream_t st)
+                   uint64_t dst_bytes, uint32_t *d_status, const uint32_t *d_crc32, const uint32_t *d_x2n, hipStream_t st)
 {
     if (n_members == 0) return HHGT_OK;
     if (src_bytes < 4 || (src_bytes & 3u) || src_bytes >= (1ull << 34) || (reinterpret_cast<uintptr_t>(d_src) & 3u)) {
@@ -407,12 +502,27 @@ int launch_inflate(const uint8_t *d_src, uint64_t src_bytes, const uint64_t *d_c
                        reinterpret_cast<const unsigned long long *>(d_out_off), d_isize, (uint32_t)n_members, d_dst,
                        dst_bytes, d_status);
     HIP_TRY(hipGetLastError());
+    if (d_crc32) {
+        hipLaunchKernelGGL(k_crc32_members, dim3((uint32_t)grid), dim3(256), 0, st, d_dst,
+                           reinterpret_cast<const unsigned long long *>(d_out_off), d_isize, d_crc32, (uint32_t)n_members,
+                           d_x2n, d_status);
+        HIP_TRY(hipGetLastError());
+    }
     return HHGT_OK;
+}
+
+// x^(2^k) mod P for k = 0..31 (host; uploaded once per context)
+void crc32_x2n_table(uint32_t *t)
+{
+    uint32_t p = 0x40000000u;  // x^1
+    t[0] = p;
+    for (int k = 1; k < 32; ++k) t[k] = p = crc_multmodp(p, p);
 }
 
 // ---- host side: member table of a BGZF byte range (RFC 1952 member with the 6-byte "BC" extra subfield) ----
 extern "C" int hhgt_bgzf_scan(const void *host, uint64_t nbytes, uint64_t max_members, uint64_t *comp_off,
-                              uint32_t *comp_len, uint32_t *isize, uint64_t *n_members, uint64_t *consumed)
+                              uint32_t *comp_len, uint32_t *isize, uint32_t *crc32, uint64_t *n_members,
+                              uint64_t *consumed)
 {
     if (!host || !n_members || !consumed || (max_members && (!comp_off || !comp_len || !isize))) return HHGT_ERR_ARG;
     const uint8_t *p = static_cast<const uint8_t *>(host);
@@ -446,6 +556,7 @@ extern "C" int hhgt_bgzf_scan(const void *host, uint64_t nbytes, uint64_t max_me
         comp_len[n] = bsize - (12u + xlen) - 8u;
         const uint8_t *t = h + bsize - 4;
         isize[n] = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (crc32) crc32[n] = t[-4] | (t[-3] << 8) | (t[-2] << 16) | ((uint32_t)t[-1] << 24);
         if (isize[n] > 65536u) {
             hhgt_set_error("bgzf scan: member at byte %llu claims %u bytes (BGZF allows 65536)", (unsigned long long)pos, isize[n]);
             return HHGT_ERR_MALFORMED;

@@ -68,28 +68,32 @@ class EncodeResult:
 
 def bgzf_scan(raw):
     """Member table of a BGZF byte string (host only; `hhgt_bgzf_scan`).  -> dict(data, comp_off, comp_len, isize,
-    consumed): offsets / lengths of the raw DEFLATE payloads, inflated sizes, bytes covered by whole members."""
+    crc32, consumed): offsets / lengths of the raw DEFLATE payloads, inflated sizes and CRC-32s from the trailers, bytes
+    covered by whole members."""
     from ._lib import load
     lib = load()
     data = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray, memoryview)) else np.ascontiguousarray(raw, dtype=np.uint8)
-    offs, lens, isz = [], [], []
+    offs, lens, isz, crcs = [], [], [], []
     pos, cap = 0, 1 << 16
     while pos < data.size:
         co = np.zeros(cap, dtype=np.uint64)
         cl = np.zeros(cap, dtype=np.uint32)
         iz = np.zeros(cap, dtype=np.uint32)
+        cr = np.zeros(cap, dtype=np.uint32)
         n, used = C.c_uint64(0), C.c_uint64(0)
         check(lib.hhgt_bgzf_scan(C.c_void_p(data.ctypes.data + pos), data.size - pos, cap, C.c_void_p(co.ctypes.data),
-                                 C.c_void_p(cl.ctypes.data), C.c_void_p(iz.ctypes.data), C.byref(n), C.byref(used)))
+                                 C.c_void_p(cl.ctypes.data), C.c_void_p(iz.ctypes.data), C.c_void_p(cr.ctypes.data),
+                                 C.byref(n), C.byref(used)))
         if n.value == 0:
             break
         offs.append(co[:n.value] + np.uint64(pos))
         lens.append(cl[:n.value])
         isz.append(iz[:n.value])
+        crcs.append(cr[:n.value])
         pos += used.value
     cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
     return dict(data=data, comp_off=cat(offs, np.uint64), comp_len=cat(lens, np.uint32), isize=cat(isz, np.uint32),
-                consumed=pos)
+                crc32=cat(crcs, np.uint32), consumed=pos)
 
 
 class Context:
@@ -210,7 +214,7 @@ class Context:
         return dst, int(bad.value)
 
     # ---- BGZF on the device -------------------------------------------------------
-    def inflate_bgzf(self, raw, return_status=False):
+    def inflate_bgzf(self, raw, return_status=False, check_crc=True):
         """raw: host bytes / uint8 array holding whole BGZF members.  The host walks the member headers
         (bgzf_scan), the compressed bytes are uploaded as they are and every member is inflated by one wave.
         -> (text uint8 tensor on the device, n_bad[, status tensor])"""
@@ -228,23 +232,25 @@ class Context:
             d_len = torch.from_numpy(tab["comp_len"]).to(self.device)
             d_out = torch.from_numpy(out_off[:-1].copy()).to(self.device)
             d_isz = torch.from_numpy(tab["isize"]).to(self.device)
+            d_crc = torch.from_numpy(tab["crc32"]).to(self.device) if check_crc else None
             dst = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)[:total]
             status = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)[:n]
             bad = C.c_uint64(0)
             check(self.lib.hhgt_inflate_members(self.h, _ptr(d_src), padded.size, _ptr(d_off), _ptr(d_len), _ptr(d_out),
-                                                _ptr(d_isz), n, _ptr(dst), total, _ptr(status), C.byref(bad),
-                                                _stream()))
+                                                _ptr(d_isz), n, _ptr(dst), total, _ptr(d_crc), _ptr(status),
+                                                C.byref(bad), _stream()))
         return (dst, int(bad.value), status) if return_status else (dst, int(bad.value))
 
     def inflate_members(self, d_src, src_bytes, d_comp_off, d_comp_len, d_out_off, d_isize, n, dst, dst_bytes, status,
-                        count_bad=True):
+                        count_bad=True, d_crc32=None):
         """`hhgt_inflate_members` on device tensors (see include/hhgt.h) -> number of members flagged in `status`
         (count_bad=False: launch only, no synchronisation, returns None — look at `status` later)"""
         bad = C.c_uint64(0)
         with torch.cuda.device(self.device):
             check(self.lib.hhgt_inflate_members(self.h, _ptr(d_src), int(src_bytes), _ptr(d_comp_off), _ptr(d_comp_len),
                                                 _ptr(d_out_off), _ptr(d_isize), int(n), _ptr(dst), int(dst_bytes),
-                                                _ptr(status), C.byref(bad) if count_bad else None, _stream()))
+                                                _ptr(d_crc32), _ptr(status), C.byref(bad) if count_bad else None,
+                                                _stream()))
         return int(bad.value) if count_bad else None
 
     # ---- synthetic workloads (bench / test tooling) -----------------------------------------------

@@ -96,7 +96,7 @@ class _DeviceBgzfBlocks:
         tab = dev.bgzf_scan(self.raw)
         if tab["consumed"] != self.raw.size:
             raise dev.HhgtError(-4, f"{path}: {self.raw.size - tab['consumed']} bytes behind the last whole BGZF member")
-        self.off, self.len, self.isz = tab["comp_off"], tab["comp_len"], tab["isize"]
+        self.off, self.len, self.isz, self.crc = tab["comp_off"], tab["comp_len"], tab["isize"], tab["crc32"]
         if block_bytes is None:
             block_bytes = min(1 << 30, (int(self.isz.sum(dtype=np.uint64)) + (9 << 20)) // (1 << 20) * (1 << 20))
         self.block_bytes = block_bytes
@@ -133,9 +133,10 @@ class _DeviceBgzfBlocks:
         d_len = torch.from_numpy(np.ascontiguousarray(self.len[m0:m1])).to(d, non_blocking=True)
         d_out = torch.from_numpy(out_off).to(d, non_blocking=True)
         d_isz = torch.from_numpy(np.ascontiguousarray(isz[m0:m1])).to(d, non_blocking=True)
+        d_crc = torch.from_numpy(np.ascontiguousarray(self.crc[m0:m1])).to(d, non_blocking=True)
         status = torch.zeros(m1 - m0, dtype=torch.int32, device=d)
         self.ctx.inflate_members(d_src, padded.size, d_off, d_len, d_out, d_isz, m1 - m0, dbuf, carry + total, status,
-                                 count_bad=False)   # no host wait here: the caller's kernels are launched next
+                                 count_bad=False, d_crc32=d_crc)   # no host wait here: the caller's kernels are launched next
         self._pending = (status, m0)
         return carry + total
 
@@ -147,7 +148,9 @@ class _DeviceBgzfBlocks:
             nz = torch.nonzero(status)
             if nz.numel():
                 k = int(nz[0])
-                raise dev.HhgtError(-7, f"BGZF member {m0 + k}: DEFLATE stream is corrupt (status {int(status[k])})")
+                code = int(status[k])
+                what = "CRC-32 of the inflated text differs from the trailer" if code == 9 else f"DEFLATE stream is corrupt (status {code})"
+                raise dev.HhgtError(-7, f"BGZF member {m0 + k}: {what}")
 
     def _cut(self, dbuf, n):
         """bytes of dbuf[:n] that are whole lines (everything at end of file)"""

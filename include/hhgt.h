@@ -195,22 +195,23 @@ int hhgt_onehot_bases_u8(hhgt_ctx *ctx, const uint8_t *d_bases, uint64_t n, cons
  * headers, the compressed bytes cross PCIe and every member (<= 64 KiB of text) is inflated by one wave.
  *
  * hhgt_bgzf_scan (host): member table of host[0, nbytes).  Fills up to max_members entries —
- * comp_off (byte offset of the raw DEFLATE payload), comp_len (its length), isize (inflated size from the
- * trailer) — and sets *n_members and *consumed (bytes covered by whole members; a member cut off by the
+ * comp_off (byte offset of the raw DEFLATE payload), comp_len (its length), isize and crc32 (inflated size and
+ * CRC-32 from the trailer) — and sets *n_members and *consumed (bytes covered by whole members; a member cut off by the
  * end of the buffer is left for the next call).  HHGT_ERR_MALFORMED if a header is not a BGZF member.
  *
  * hhgt_inflate_members (device): inflates member i from d_src + d_comp_off[i] to d_dst + d_out_off[i]
  * (d_out_off = exclusive prefix sum of isize, computed by the caller).  d_src must be 4-byte aligned and
  * src_bytes a multiple of 4 (pad the upload).  d_status[i] = 0 on success, else a non-zero code
  * (1 block type, 2 stored block, 3 code table, 4 invalid code, 5 distance, 6 output overrun, 7 input overrun,
- * 8 size != ISIZE).  *n_bad (host, optional, syncs) = number of members with a non-zero status.  CRC32 is not checked.
+ * 8 size != ISIZE, 9 CRC-32 of the text != d_crc32[i] — checked by a second kernel when d_crc32 is given, as htslib's
+ * bgzf.c does).  *n_bad (host, optional, syncs) = number of members with a non-zero status.
  * ------------------------------------------------------------------------------------------- */
 int hhgt_bgzf_scan(const void *host, uint64_t nbytes, uint64_t max_members, uint64_t *comp_off, uint32_t *comp_len,
-                   uint32_t *isize, uint64_t *n_members, uint64_t *consumed);
+                   uint32_t *isize, uint32_t *crc32 /* optional */, uint64_t *n_members, uint64_t *consumed);
 int hhgt_inflate_members(hhgt_ctx *ctx, const void *d_src, uint64_t src_bytes, const uint64_t *d_comp_off,
                          const uint32_t *d_comp_len, const uint64_t *d_out_off, const uint32_t *d_isize,
-                         uint64_t n_members, void *d_dst, uint64_t dst_bytes, uint32_t *d_status, uint64_t *n_bad,
-                         void *stream);
+                         uint64_t n_members, void *d_dst, uint64_t dst_bytes, const uint32_t *d_crc32 /* optional */,
+                         uint32_t *d_status, uint64_t *n_bad, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-stage device timing (HIP events on the launch stream).  Stages are indexed by HHGT_STAGE_*.

@@ -30,6 +30,7 @@ def test_scan_matches_writer(tmp_path):
     assert tab["consumed"] == len(raw)
     assert int(tab["isize"].sum()) == len(text)
     assert tab["isize"][-1] == 0 and tab["comp_len"][-1] == 2          # the EOF marker member
+    assert int(tab["crc32"][0]) == zlib.crc32(text[:0xFF00]) and int(tab["crc32"][-1]) == 0
     out = b"".join(zlib.decompress(raw[int(o):int(o) + int(l)], -15) for o, l in zip(tab["comp_off"], tab["comp_len"]))
     assert out == text
 

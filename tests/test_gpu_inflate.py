@@ -185,3 +185,24 @@ def test_converter_with_device_inflate_writes_the_same_h5(ctx, tmp_path, golden_
         assert conv.stats["chr_4"].is_bgzf and conv.stats["chr_4"].n_kept > 1000
         files[mode] = open(conv.h5_path, "rb").read()
     assert files["0"] == files["1"]
+
+
+def test_crc32_of_the_text_is_checked(ctx):
+    """htslib rejects a member whose inflated bytes do not match the trailer CRC-32 (bgzf.c); so does the device path:
+    a flipped trailer, and a flipped byte inside a stored block (inflates fine, to different text), are status 9"""
+    rng = np.random.default_rng(12)
+    chunks = [vcf_like(30, 200, 40 + i) for i in range(6)] + [b"", bytes(rng.integers(0, 256, size=60000, dtype=np.uint8)), b"z", b"q" * 4096, b"r" * 4097, b"s" * 8191, bytes(range(256)) * 17]
+    raw = bytearray(bgzf(chunks[:4], 6) + bgzf(chunks[4:6], 0) + bgzf(chunks[6:], 6))
+    tab = dev.bgzf_scan(bytes(raw))
+    assert [int(c) for c in tab["crc32"]] == [zlib.crc32(c) for c in chunks]
+    text, bad = ctx.inflate_bgzf(bytes(raw))
+    assert bad == 0 and text.cpu().numpy().tobytes() == b"".join(chunks)
+    o1 = int(tab["comp_off"][1]) + int(tab["comp_len"][1])                 # member 1: its CRC field
+    raw[o1] ^= 0x10
+    o5 = int(tab["comp_off"][5]) + 5 + 1000                                # member 5: a byte of the stored block's data
+    raw[o5] ^= 0x01
+    text, bad, status = ctx.inflate_bgzf(bytes(raw), return_status=True)
+    st = status.cpu().numpy().tolist()
+    assert bad == 2 and st[1] == 9 and st[5] == 9 and sum(1 for x in st if x) == 2
+    _, bad = ctx.inflate_bgzf(bytes(raw), check_crc=False)
+    assert bad == 0

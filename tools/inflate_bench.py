@@ -42,7 +42,7 @@ for _ in range(N):
     out, bad = ctx.inflate_bgzf(raw)
 torch.cuda.synchronize()
 t_call = (time.perf_counter() - t0) / N
-kern = ctx.profile_read()["inflate"]["ms"] / N
+kern = ctx.profile_read()["inflate"]["ms"] / N   # inflate + CRC-32 kernels
 print(json.dumps(dict(variants=V, samples=S, level=level, text_GB=len(text) / 1e9, bgzf_GB=len(raw) / 1e9, members=len(members),
                       ms_kernel=kern, text_GBps_kernel=len(text) / kern / 1e6, ms_call_with_upload=t_call * 1e3,
                       host_scan_ms=t_scan * 1e3, zlib_one_core_GBps=n / t_cpu / 1e9,
