@@ -24,6 +24,7 @@ struct Task {
     uint32_t dst_len;
     int fd = -1;            // >= 0: an uncompressed piece, read with pread(fd, dst, dst_len, file_off)
     uint64_t file_off = 0;
+    bool check_crc = false;  // BGZF member: compare crc32(dst) with the trailer behind src
 };
 
 struct Block {
@@ -39,6 +40,7 @@ struct hhgt_reader {
     size_t map_len = 0;
     size_t in_pos = 0;  // next unread compressed byte
     bool is_gzip = false, is_bgzf = false;
+    bool check_crc = true;   // HHGT_BGZF_NO_CRC=1 skips the per-member CRC32 (htslib always checks it)
     size_t block_bytes = 0;
     bool pinned = false;
     std::vector<Block> ring;
@@ -96,6 +98,13 @@ static int inflate_raw(z_stream *zs, const Task &t)
     zs->avail_out = t.dst_len;
     int rc = inflate(zs, Z_FINISH);
     if (rc != Z_STREAM_END || zs->avail_out != 0) return -1;
+    if (t.check_crc) {
+        // the member's trailer (CRC32, ISIZE) follows the payload; htslib's bgzf.c rejects a member whose text does
+        // not hash to it ("CRC32 checksum mismatch")
+        const uint8_t *tr = t.src + t.src_len;
+        const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), t.dst, t.dst_len) != want) return -2;
+    }
     return 0;
 }
 
@@ -105,7 +114,8 @@ static void run_tasks(hhgt_reader *r, z_stream *zs)
         const uint64_t t = r->ticket.fetch_add(1);
         const uint64_t gen = t >> 32, i = t & 0xFFFFFFFFull;
         if (gen != r->open_gen.load() || i >= r->n_tasks.load()) break;
-        if (inflate_raw(zs, r->tasks[i]) != 0) r->task_err.store(1);
+        const int rc = inflate_raw(zs, r->tasks[i]);
+        if (rc != 0) r->task_err.store(rc == -2 ? 2 : 1);
         r->done_tasks.fetch_add(1);
     }
 }
@@ -209,11 +219,16 @@ static long long fill_bgzf(hhgt_reader *r, uint8_t *dst, size_t cap)
                          ((uint32_t)p[total - 1] << 24);
         if (isize > 65536) return -1;
         if (produced + isize > cap) break;
-        if (isize) r->tasks.push_back(Task{p + 18, (uint32_t)(total - 18 - 8), dst + produced, isize});
+        if (isize) {
+            Task t{p + 18, (uint32_t)(total - 18 - 8), dst + produced, isize};
+            t.check_crc = r->check_crc;
+            r->tasks.push_back(t);
+        }
         produced += isize;
         r->in_pos += total;
     }
-    if (run_batch(r) < 0) return -1;
+    const long long rb = run_batch(r);
+    if (rb < 0) return rb;
     return (long long)produced;
 }
 
@@ -239,7 +254,7 @@ static long long run_batch(hhgt_reader *r)
         std::unique_lock<std::mutex> lk(r->pmu);
         r->dcv.wait(lk, [&] { return r->done_tasks.load() >= r->tasks.size(); });
     }
-    return r->task_err.load() ? -1 : 0;
+    return r->task_err.load() == 2 ? -4 : (r->task_err.load() ? -1 : 0);
 }
 
 static void producer_main(hhgt_reader *r)
@@ -269,7 +284,7 @@ static void producer_main(hhgt_reader *r)
             if (got < 0) {
                 std::lock_guard<std::mutex> lk(r->mu);
                 r->error = HHGT_ERR_IO;
-                r->errmsg = got == -2 ? "truncated compressed input" : got == -3 ? "corrupt BGZF block header" : "inflate failed";
+                r->errmsg = got == -2 ? "truncated compressed input" : got == -3 ? "corrupt BGZF block header" : got == -4 ? "BGZF member: CRC32 checksum mismatch" : "inflate failed";
                 r->eof = true;
                 r->cv.notify_all();
                 return;
@@ -348,6 +363,10 @@ extern "C" int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_th
     }
     r->is_gzip = r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b;
     r->is_bgzf = r->is_gzip && looks_bgzf(r->map, r->map_len);
+    {
+        const char *e = getenv("HHGT_BGZF_NO_CRC");
+        r->check_crc = !(e && *e && *e != '0');
+    }
     r->block_bytes = (size_t)block_bytes;
     r->ring.resize((size_t)n_blocks);
     // pinned when a HIP device exists (the copy engine can then DMA straight out of the ring);

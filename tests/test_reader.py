@@ -83,3 +83,21 @@ def test_errors(tmp_path):
     open(q, "wb").write(b"x" * (3 << 20))
     with pytest.raises(HhgtError, match="longer than"):
         collect(q, block_bytes=1 << 20)
+
+
+def test_bgzf_crc_mismatch_is_an_error(tmp_path, monkeypatch):
+    """htslib's bgzf.c fails a member whose text does not hash to the trailer CRC32; so does the host reader
+    (HHGT_BGZF_NO_CRC=1 skips the check)"""
+    from haplohyped_varawareml_amd._lib import HhgtError
+    text = b"".join(b"chr1\t%d\t.\tA\tG\t.\t.\t.\tGT\t0|1\n" % i for i in range(20000))
+    p = str(tmp_path / "c.vcf.gz")
+    write_bgzf(p, text, block_size=20000)
+    raw = bytearray(open(p, "rb").read())
+    assert b"".join(collect(p)[0]) == text and collect(p)[1]
+    bsize = raw[16] | (raw[17] << 8)
+    raw[bsize + 1 - 8] ^= 0x40                 # CRC32 field of the first member
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(HhgtError, match="CRC32"):
+        collect(p)
+    monkeypatch.setenv("HHGT_BGZF_NO_CRC", "1")
+    assert b"".join(collect(p)[0]) == text
