@@ -11,6 +11,9 @@
  * buffers cut at line boundaries, from which hhgt_reader_copy_async issues hipMemcpyAsync on the
  * caller's stream (double buffering: the copy of block k+1 overlaps the kernels of block k).
  * No tabix index is needed: region selection happens on the device (hhgt_encode_text's `region`).
+ * Every BGZF member's text is hashed (zlib crc32) and compared with the member's trailer, as htslib's
+ * bgzf.c does; a mismatch fails the read with "CRC32 checksum mismatch" (environment
+ * HHGT_BGZF_NO_CRC=1 skips the check).
  */
 #ifndef HHGT_READER_H
 #define HHGT_READER_H
