@@ -13,6 +13,9 @@
  *     compression_opts=(2,2,0,0,5,1,2))  src/haplohyped/vcf_to_h5.py:134-135   -> Blosc2-framed chunks), and
  *     = hdf5plugin Blosc2 filter -> c-blosc2 shuffle + LZ4 block encode  hhgt_decompress_chunks (read side,
  *                                                                        src/utils/h5_reader.py:37-41)
+ *   htslib bgzf_read_block + inflate under the reader                  hhgt_bgzf_scan + hhgt_inflate_members
+ *     cpp/vcfpp.h:1381 (open), :1468 (record reads)                      (opt-in; the default keeps BGZF on the
+ *                                                                        host: include/hhgt_reader.h)
  *
  * Conventions: plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HBM) on the
  * context's device; everything else is host memory.  `stream` is a hipStream_t passed as void*
