@@ -69,6 +69,22 @@ __device__ __forceinline__ bool huff_build(const uint8_t *lens, uint32_t nsym, u
 }
 
 // next symbol of the code in t from the low bits of `bits`; nbits = its length.  -1: no code matches.
+// As huff_decode, with the first 64 sorted symbols also held one per lane in `front` (the short, frequent codes
+// sort first): a hit there is a second readlane instead of an LDS round trip.
+__device__ __forceinline__ int huff_decode_front(const HuffLane &t, const uint16_t *syms, uint32_t front, uint32_t bits,
+                                                 uint32_t shiftv, uint32_t &nbits)
+{
+    const uint32_t rev = __builtin_bitreverse32(bits);
+    const uint32_t d = (rev >> shiftv) - t.first;
+    const unsigned long long m = __ballot(d < t.cnt);
+    if (m == 0ull) return -1;
+    const uint32_t L = (uint32_t)__builtin_ctzll(m);
+    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)(t.offs + d), (int)L);
+    nbits = L;
+    if (idx < 64u) return __builtin_amdgcn_readlane((int)front, (int)idx);
+    return (int)sgpr(syms[idx]);
+}
+
 __device__ __forceinline__ int huff_decode(const HuffLane &t, const uint16_t *syms, uint32_t bits, uint32_t shiftv,
                                            uint32_t &nbits)
 {
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(256) void k_inflate_members(const uint8_t *__restri
             }
         }
         // ---- symbols of this block ----
+        const uint32_t ll_front = ll_syms[lane], dd_front = dd_syms[lane & 31u];
         for (;;) {
             if (wi > end_word + 2u) {
                 err = INF_INPUT_OVERRUN;
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(256) void k_inflate_members(const uint8_t *__restri
             }
             refill();
             uint32_t nb;
-            const int sym = huff_decode(LL, ll_syms, (uint32_t)bb, shiftv, nb);
+            const int sym = huff_decode_front(LL, ll_syms, ll_front, (uint32_t)bb, shiftv, nb);
             if (sym < 0) {
                 err = INF_BAD_CODE;
                 break;
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(256) void k_inflate_members(const uint8_t *__restri
                 len = ((4u + (li & 3u)) << eb) + 3u + take(eb);
             }
             refill();
-            const int ds = huff_decode(DD, dd_syms, (uint32_t)bb, shiftv, nb);
+            const int ds = huff_decode_front(DD, dd_syms, dd_front, (uint32_t)bb, shiftv, nb);
             if (ds < 0 || ds > 29) {
                 err = INF_BAD_CODE;
                 break;
