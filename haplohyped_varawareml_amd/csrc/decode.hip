@@ -83,7 +83,7 @@ __device__ __forceinline__ bool lz4_wave_decode(const uint8_t *cin, uint32_t csi
         // extension byte all sit in the 19 bytes at ip.  Lane k (k <= 15) gathers the two aligned dwords around byte
         // ip + k and forms the 32-bit window starting there, so every header field is one readlane away: the token
         // from lane 0, offset + extension byte from lane ll + 1; byte 1 of lane k's window is literal k.  The kernel
-        // is bound by scalar-ALU issue (one SALU op per cycle per CU, shared by all its waves), so the point of this
+        // is bound by scalar-ALU issue (the SQ counters show 1.0 scalar op per cycle per SIMD), so the point of this
         // shape is few scalar instructions per sequence.  (cin has >= 24 readable bytes past csize.)
         {
             const uint32_t q = ip + (lane < 15u ? lane : 15u);
