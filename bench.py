@@ -86,6 +86,9 @@ def build_shards(ctx, args, rank, world):
         sh.off = torch.zeros(sh.n_chunks + 1, dtype=torch.int64, device=d)
         sh.total = 0
         sh.cmp_done = None
+        sh.cursor = torch.zeros(1, dtype=torch.int64, device=d)
+        sh.pending = dev.PendingEncode()
+        sh.max_lines = V + 64
         shards.append(sh)
     return shards
 
@@ -94,10 +97,16 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
     """encode + pad + compress of every shard.  With two streams the (issue-bound) LZ4 kernel of shard k
     overlaps the (HBM-bound) index/encode kernels of shard k+1 — the same software pipeline the streaming
     converter uses; every kernel still runs once per shard per step."""
+    def encode(sh):
+        # asynchronous chain: the append position and every count stay on the device (hhgt_encode_text_async), so
+        # the host never waits inside a step and the encode stream runs ahead of the compress stream by itself
+        sh.cursor.zero_()
+        ctx.encode_text_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
+        ctx.pad_tail_cursor(sh.res, sh.cursor)
+
     if streams is None:
         for sh in shards:
-            ctx.encode_text(sh.text, S, region=sh.contig, v_base=0, out=sh.res)
-            ctx.pad_tail(sh.res)
+            encode(sh)
             ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2,
                          dst=sh.dst, chunk_off=sh.off, sync=False)
         return
@@ -107,8 +116,7 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
         with torch.cuda.stream(s_enc):
             if sh.cmp_done is not None:
                 s_enc.wait_event(sh.cmp_done)          # G of this shard is free again
-            ctx.encode_text(sh.text, S, region=sh.contig, v_base=0, out=sh.res)
-            ctx.pad_tail(sh.res)
+            encode(sh)
             sh.ready = s_enc.record_event()
 
     def cmp_(sh):
@@ -118,9 +126,8 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
                          dst=sh.dst, chunk_off=sh.off, sync=False)
             sh.cmp_done = s_cmp.record_event()
 
-    # hhgt_encode_text blocks the host (it returns counts).  With `lookahead` shards encoded ahead, the compress of
-    # shard k is queued BEFORE the host blocks in the encode of shard k + lookahead, so the compress stream always
-    # has its next kernel waiting and the encode chain's launch gaps never sit between two LZ4 kernels.
+    # nothing blocks the host: the whole step is queued at once; `lookahead` only bounds how far the encode stream may
+    # run ahead of the compress stream (G of shard k is rewritten by the next step's encode)
     n = len(shards)
     for i in range(min(lookahead, n)):
         enc(shards[i])
@@ -264,7 +271,10 @@ def main():
 
     # sizes for the roofline (algorithmic bytes), this rank
     comp_bytes = sum(int(sh.off[-1].item()) for sh in shards)
-    g_bytes = sum(sh.res.stats["n_kept"] * 2 * S for sh in shards)          # V' * 2S
+    for sh in shards:
+        rec = sh.pending.wait()                                             # raises on malformed text / capacity
+        assert rec.cursor_after == sh.V, (sh.contig, rec.cursor_after, sh.V)
+    g_bytes = sum(sh.V * 2 * S for sh in shards)                             # V' * 2S (every synthetic record is kept)
     alg = {
         "index": text_bytes, "fixed": 0, "encode": sum(sh.V * 4 * S for sh in shards) + g_bytes,
         "lz4": g_bytes + comp_bytes, "frame": 2 * comp_bytes,

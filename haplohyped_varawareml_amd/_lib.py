@@ -24,7 +24,7 @@ class HhgtError(RuntimeError):
 
 
 class Layout(C.Structure):
-    _fields_ = [("n_samples", C.c_int32), ("sc", C.c_int32), ("vc", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_samples", C.c_int32), ("sc", C.c_int32), ("vc", C.c_int32), ("ring", C.c_int32),
                 ("v_capacity", C.c_uint64)]
 
 
@@ -42,6 +42,20 @@ class EncodeStats(C.Structure):
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+RESULT_RUNS = 16
+
+
+class EncodeResultRec(C.Structure):     # hhgt_encode_result
+    _fields_ = [("stats", EncodeStats), ("cursor_before", C.c_uint64), ("cursor_after", C.c_uint64),
+                ("n_lines_over", C.c_uint64), ("err_density", C.c_uint64), ("run_first", C.c_uint64 * RESULT_RUNS),
+                ("run_names", (C.c_char * 32) * RESULT_RUNS), ("v_capacity", C.c_uint64), ("done", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+    def chrom_runs(self):
+        n = min(int(self.stats.n_chrom_runs), RESULT_RUNS)
+        return [(int(self.run_first[i]), bytes(self.run_names[i]).split(b"\0")[0].decode()) for i in range(n)]
 
 
 _lib = None
@@ -72,6 +86,10 @@ def load():
     L.hhgt_layout_offset.argtypes = [C.POINTER(Layout), C.c_uint32, u64]
     L.hhgt_encode_text.argtypes = [vp, vp, u64, C.c_char_p, C.POINTER(Layout), u64, vp, vp, vp, vp, vp,
                                    C.POINTER(EncodeStats), vp]
+    L.hhgt_encode_text_async.argtypes = [vp, vp, u64, C.c_char_p, C.POINTER(Layout), vp, C.c_uint32, vp, vp, vp, vp, vp,
+                                         vp, vp]
+    L.hhgt_encode_result_status.argtypes = [vp]
+    L.hhgt_pad_tail_cursor.argtypes = [vp, C.POINTER(Layout), vp, vp, vp]
     L.hhgt_encode_chrom_runs.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(C.c_uint32)]
     L.hhgt_pad_tail.argtypes = [vp, C.POINTER(Layout), u64, u64, u64, vp, vp]
     L.hhgt_set_clevel.argtypes = [vp, i32]

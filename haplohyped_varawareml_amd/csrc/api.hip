@@ -70,15 +70,29 @@ extern "C" int hhgt_ctx_create(int device, hhgt_ctx **out)
     HIP_TRY(hipSetDevice(device));
     hhgt_ctx *c = new hhgt_ctx();
     c->device = device;
-    HIP_TRY(hipGetDeviceProperties(&c->prop, device));
-    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+    // from here on a failure must not leak the context (hhgt_ctx_destroy copes with a half-built one)
+    int rc = HHGT_OK;
+    hipError_t e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) {
+        hhgt_set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        rc = HHGT_ERR_HIP;
+    } else if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
         hhgt_set_error("device %d is %s; libhhgt carries gfx950 code objects only", device, c->prop.gcnArchName);
-        delete c;
-        return HHGT_ERR_NO_DEVICE;
+        rc = HHGT_ERR_NO_DEVICE;
     }
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(DevCounters), hipHostMallocDefault));
-    TRY(c->counters.ensure(sizeof(DevCounters)));
-    TRY(c->region.ensure(sizeof(RegionFilter)));
+    if (rc == HHGT_OK && (e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(DevCounters), hipHostMallocDefault)) != hipSuccess) {
+        hhgt_set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+        rc = HHGT_ERR_HIP;
+    }
+    if (rc == HHGT_OK && (e = hipHostMalloc(reinterpret_cast<void **>(&c->h_result_pinned), sizeof(hhgt_encode_result), hipHostMallocDefault)) != hipSuccess) {
+        hhgt_set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+        rc = HHGT_ERR_HIP;
+    }
+    if (rc == HHGT_OK) rc = c->counters.ensure(sizeof(DevCounters));
+    if (rc != HHGT_OK) {
+        hhgt_ctx_destroy(c);
+        return rc;
+    }
     *out = c;
     return HHGT_OK;
 }
@@ -90,11 +104,12 @@ extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&c->slots, &c->counts, &c->prefix, &c->nl, &c->scan_tmp, &c->l_soff, &c->l_lend, &c->l_pos,
                       &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff,
-                      &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_off,
-                      &c->counters, &c->region, &c->lz_scratch, &c->lz_csize, &c->fr_bsize, &c->fr_csize,
+                      &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_names,
+                      &c->counters, &c->cursor, &c->result, &c->lz_scratch, &c->lz_csize, &c->fr_bsize, &c->fr_csize,
                       &c->fr_flags, &c->dec_bad, &c->oh_ovl, &c->oh_lut, &c->crc_x2n};
     for (DevBuf *b : bufs) b->release();
     if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->h_result_pinned) hipHostFree(c->h_result_pinned);
     for (auto &p : c->pending) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
@@ -188,6 +203,13 @@ static int make_layout(const hhgt_layout *lay, LayoutDev *L)
     }
     L->S = (uint32_t)lay->n_samples;
     L->v_capacity = lay->v_capacity;
+    L->ring = 0;
+    L->pad_ = 0;
+    if (lay->ring < 0 || (lay->ring > 0 && (lay->vc <= 0 || lay->v_capacity != (uint64_t)lay->ring * (uint64_t)lay->vc))) {
+        hhgt_set_error("layout: a ring needs vc > 0 and v_capacity == ring * vc");
+        return HHGT_ERR_ARG;
+    }
+    L->ring = (uint32_t)lay->ring;
     if (lay->vc == 0) {
         L->Vc = lay->v_capacity ? lay->v_capacity : TILE_V;
     } else {
@@ -262,7 +284,214 @@ static int parse_region_host(const char *region, RegionFilter *rf)
 }
 
 // ---- encode ---------------------------------------------------------------------------------------
-#define MAX_CHROM_RUNS 4096u
+// device-side epilogue of one encode call: advance the cursor, assemble the result record (counts, CHROM runs)
+__global__ void k_encode_finish(DevCounters *cnt, uint64_t *cursor, const uint64_t *__restrict__ run_first,
+                                const uint8_t *__restrict__ run_names, uint64_t v_capacity, hhgt_encode_result *res)
+{
+    const uint32_t t = threadIdx.x;
+    const uint64_t before = *cursor;
+    const uint64_t kept = cnt->n_kept;
+    __syncthreads();
+    if (t == 0) {
+        *cursor = before + kept;
+        cnt->cursor_after = before + kept;
+        res->stats.n_lines = cnt->n_lines;
+        res->stats.n_records = cnt->n_records;
+        res->stats.n_kept = kept;
+        res->stats.n_drop_region = cnt->n_drop_region;
+        res->stats.n_drop_filter = cnt->n_drop_filter;
+        res->stats.n_haploid_padded = cnt->n_haploid;
+        res->stats.n_malformed = cnt->n_malformed;
+        res->stats.n_general_lines = cnt->n_general;
+        res->stats.n_chrom_runs = cnt->n_chrom_runs;
+        res->cursor_before = before;
+        res->cursor_after = before + kept;
+        res->n_lines_over = cnt->err_lines;
+        res->err_density = cnt->err_density;
+        res->v_capacity = v_capacity;
+        res->done = 1u;
+        res->reserved = 0u;
+    }
+    const uint64_t n_runs = cnt->n_chrom_runs;
+    if (t < HHGT_RESULT_RUNS) res->run_first[t] = t < n_runs ? run_first[t] : 0ull;
+    for (uint32_t q = t; q < HHGT_RESULT_RUNS * 32u; q += blockDim.x)
+        res->run_names[q >> 5][q & 31u] = (q >> 5) < n_runs ? (char)run_names[q] : 0;
+}
+
+__global__ void k_set_u64(uint64_t *p, uint64_t v) { *p = v; }
+
+static int encode_check_args(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const hhgt_layout *lay, LayoutDev *L,
+                             const char *region, RegionFilter *rf, void *d_G)
+{
+    TRY(make_layout(lay, L));
+    if (nbytes >= 0xFFFFFFF0ull) {
+        hhgt_set_error("encode: text block of %llu bytes; split it below 4 GiB at a line boundary",
+                       (unsigned long long)nbytes);
+        return HHGT_ERR_ARG;
+    }
+    if (nbytes && (!d_text || (reinterpret_cast<uintptr_t>(d_text) & 15u))) {
+        hhgt_set_error("encode: d_text must be a 16-byte aligned device pointer");
+        return HHGT_ERR_ARG;
+    }
+    if (L->S > 0 && !d_G) {
+        hhgt_set_error("encode: d_G is NULL");
+        return HHGT_ERR_ARG;
+    }
+    (void)c;
+    return parse_region_host(region, rf);
+}
+
+// stage 1: newline index of the block -> prefix[n_regions] holds the line count (device)
+static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, DevCounters *cnt,
+                              hipStream_t st)
+{
+    TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
+    TRY(c->counts.ensure((size_t)n_regions * 4));
+    TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
+    TRY(c->scan_tmp.ensure(scan_tmp_elems(n_regions) * 4));
+    TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, cnt, st));
+    TRY(launch_scan_exclusive_u32(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), n_regions,
+                                  c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+    return HHGT_OK;
+}
+
+// stages 2..: everything behind the index, sized by max_lines, counts and append position read on the device
+static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, uint32_t max_lines,
+                             const RegionFilter &rf, const LayoutDev &L, const uint64_t *d_cursor, void *d_G, uint32_t *d_start, uint32_t *d_stop,
+                             uint8_t *d_ref, uint8_t *d_alt, DevCounters *cnt, hipStream_t st)
+{
+    const uint32_t *d_nlines = c->prefix.as<uint32_t>() + n_regions;
+    const size_t nl4 = ((size_t)max_lines + 1) * 4;
+    TRY(c->nl.ensure(nl4));
+    TRY(c->scan_tmp.ensure(scan_tmp_elems(max_lines) * 4));
+    DevBuf *per_line[] = {&c->l_soff, &c->l_lend, &c->l_pos, &c->l_refalt, &c->l_flags, &c->l_keep,
+                          &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff, &c->k_lend, &c->k_meta,
+                          &c->redo_list, &c->redo_flag};
+    for (DevBuf *b : per_line) TRY(b->ensure(nl4));
+    TRY(c->run_first.ensure(MAX_CHROM_RUNS * 8));
+    TRY(c->run_names.ensure(MAX_CHROM_RUNS * 32));
+    {
+        StageTimer t(c, st, HHGT_STAGE_INDEX);
+        TRY(launch_compact_newlines(c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(),
+                                    n_regions, c->nl.as<uint32_t>(), max_lines, st));
+        t.stop();
+    }
+    if (max_lines == 0) return HHGT_OK;
+    {
+        StageTimer t(c, st, HHGT_STAGE_FIXED);
+        TRY(launch_parse_fixed(text, nbytes, c->nl.as<uint32_t>(), d_nlines, max_lines, rf, L.S,
+                               c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(),
+                               c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(), c->l_keep.as<uint32_t>(),
+                               c->l_cnew.as<uint32_t>(), cnt, st));
+        TRY(launch_scan_exclusive_u32(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), max_lines,
+                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+        TRY(launch_scan_exclusive_u32(c->l_cnew.as<uint32_t>(), c->l_crun.as<uint32_t>(), max_lines,
+                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+        HIP_TRY(hipMemsetAsync(c->redo_flag.p, 0, (size_t)max_lines * 4, st));
+        TRY(launch_compact_kept(text, nbytes, c->nl.as<uint32_t>(), d_nlines, max_lines, c->l_soff.as<uint32_t>(),
+                                c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(), c->l_refalt.as<uint32_t>(),
+                                c->l_flags.as<uint32_t>(), c->l_kidx.as<uint32_t>(), c->l_crun.as<uint32_t>(),
+                                c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(), c->k_meta.as<uint32_t>(),
+                                c->redo_list.as<uint32_t>(), c->run_first.as<uint64_t>(), c->run_names.as<uint8_t>(),
+                                MAX_CHROM_RUNS, d_cursor, L.v_capacity, L.ring, d_start, d_stop, d_ref, d_alt, cnt, st));
+        t.stop();
+    }
+    if (L.S > 0) {
+        StageTimer t(c, st, HHGT_STAGE_ENCODE);
+        TRY(launch_encode_tiles(text, nbytes, c->k_soff.as<uint32_t>(), c->k_meta.as<uint32_t>(), max_lines, d_cursor,
+                                L, static_cast<int8_t *>(d_G), c->redo_list.as<uint32_t>(),
+                                c->redo_flag.as<uint32_t>(), cnt, st));
+        t.stop();
+        StageTimer t2(c, st, HHGT_STAGE_GENERAL);
+        TRY(launch_encode_general(text, nbytes, c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(),
+                                  c->k_meta.as<uint32_t>(), c->redo_list.as<uint32_t>(), d_cursor, L,
+                                  static_cast<int8_t *>(d_G), cnt, c->prop.multiProcessorCount, st));
+        t2.stop();
+    }
+    return HHGT_OK;
+}
+
+static int encode_finish(hhgt_ctx *c, uint64_t *d_cursor, const LayoutDev &L, DevCounters *cnt, hipStream_t st)
+{
+    TRY(c->run_first.ensure(MAX_CHROM_RUNS * 8));
+    TRY(c->run_names.ensure(MAX_CHROM_RUNS * 32));
+    TRY(c->result.ensure(sizeof(hhgt_encode_result)));
+    hipLaunchKernelGGL(k_encode_finish, dim3(1), dim3(256), 0, st, cnt, d_cursor, c->run_first.as<uint64_t>(),
+                       c->run_names.as<uint8_t>(), L.ring ? 0ull : L.v_capacity, c->result.as<hhgt_encode_result>());
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_encode_result_status(const hhgt_encode_result *r)
+{
+    if (!r) return HHGT_ERR_ARG;
+    if (!r->done) {
+        hhgt_set_error("encode: the result record is not complete yet (synchronise the stream first)");
+        return HHGT_ERR_ARG;
+    }
+    if (r->err_density) {
+        hhgt_set_error("encode: more than %u newlines inside one %u-byte region (not VCF text)", INDEX_CAP, INDEX_REGION);
+        return HHGT_ERR_LINE_DENSITY;
+    }
+    if (r->n_lines_over) {
+        hhgt_set_error("encode: %llu lines beyond max_lines were not encoded", (unsigned long long)r->n_lines_over);
+        return HHGT_ERR_CAPACITY;
+    }
+    if (r->stats.n_malformed) {
+        hhgt_set_error("Error parsing VCF file: %llu malformed record(s) (too few columns, bad POS, FORMAT without GT)",
+                       (unsigned long long)r->stats.n_malformed);
+        return HHGT_ERR_MALFORMED;
+    }
+    if (r->v_capacity && r->cursor_after > r->v_capacity) {
+        hhgt_set_error("encode: %llu kept records at v_base %llu exceed v_capacity %llu",
+                       (unsigned long long)r->stats.n_kept, (unsigned long long)r->cursor_before,
+                       (unsigned long long)r->v_capacity);
+        return HHGT_ERR_CAPACITY;
+    }
+    if (r->stats.n_chrom_runs > MAX_CHROM_RUNS) {
+        hhgt_set_error("encode: %llu CHROM runs in one text block (limit %u): the input is not sorted by contig",
+                       (unsigned long long)r->stats.n_chrom_runs, MAX_CHROM_RUNS);
+        return HHGT_ERR_CAPACITY;
+    }
+    return HHGT_OK;
+}
+
+static void empty_result(hhgt_encode_result *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->done = 1u;
+}
+
+extern "C" int hhgt_encode_text_async(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
+                                      const hhgt_layout *lay, uint64_t *d_cursor, uint32_t max_lines, void *d_G,
+                                      uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt,
+                                      hhgt_encode_result *h_result, void *stream)
+{
+    if (!c || !d_cursor) return HHGT_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    LayoutDev L;
+    RegionFilter rf;
+    TRY(encode_check_args(c, d_text, nbytes, lay, &L, region, &rf, d_G));
+    const uint8_t *text = static_cast<const uint8_t *>(d_text);
+    DevCounters *cnt = c->counters.as<DevCounters>();
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));
+    const uint32_t n_regions = (uint32_t)((nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION);
+    if (nbytes) {
+        {
+            StageTimer t(c, st, HHGT_STAGE_INDEX);
+            TRY(encode_stage_index(c, text, nbytes, n_regions, cnt, st));
+            t.stop();
+        }
+        TRY(encode_stage_rest(c, text, nbytes, n_regions, max_lines, rf, L, d_cursor, d_G, d_start, d_stop, d_ref, d_alt, cnt, st));
+    }
+    TRY(encode_finish(c, d_cursor, L, cnt, st));
+    if (h_result) {
+        h_result->done = 0u;
+        HIP_TRY(hipMemcpyAsync(h_result, c->result.p, sizeof(hhgt_encode_result), hipMemcpyDeviceToHost, st));
+    }
+    return HHGT_OK;
+}
 
 extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
                                 const hhgt_layout *lay, uint64_t v_base, void *d_G, uint32_t *d_start,
@@ -274,149 +503,65 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
     HIP_TRY(hipSetDevice(c->device));
     if (stats) memset(stats, 0, sizeof(*stats));
     LayoutDev L;
-    TRY(make_layout(lay, &L));
-    if (nbytes >= 0xFFFFFFF0ull) {
-        hhgt_set_error("encode: text block of %llu bytes; split it below 4 GiB at a line boundary",
-                       (unsigned long long)nbytes);
-        return HHGT_ERR_ARG;
-    }
-    if (nbytes && (!d_text || (reinterpret_cast<uintptr_t>(d_text) & 15u))) {
-        hhgt_set_error("encode: d_text must be a 16-byte aligned device pointer");
-        return HHGT_ERR_ARG;
-    }
-    if (L.S > 0 && !d_G) {
-        hhgt_set_error("encode: d_G is NULL");
-        return HHGT_ERR_ARG;
-    }
     RegionFilter rf;
-    TRY(parse_region_host(region, &rf));
+    TRY(encode_check_args(c, d_text, nbytes, lay, &L, region, &rf, d_G));
     c->run_first_kept.clear();
-    c->run_names.clear();
+    c->run_names_host.clear();
     if (nbytes == 0) return HHGT_OK;
 
     const uint8_t *text = static_cast<const uint8_t *>(d_text);
     DevCounters *cnt = c->counters.as<DevCounters>();
+    TRY(c->cursor.ensure(8));
     HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));
-    HIP_TRY(hipMemcpyAsync(c->region.p, &rf, sizeof(rf), hipMemcpyHostToDevice, st));
-
-    // ---- stage: newline index
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, c->cursor.as<uint64_t>(), v_base);
     const uint32_t n_regions = (uint32_t)((nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION);
-    TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
-    TRY(c->counts.ensure((size_t)n_regions * 4));
-    TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
-    TRY(c->scan_tmp.ensure(scan_tmp_elems(n_regions) * 4));
     uint32_t n_lines = 0;
     {
+        // the synchronous form sizes everything by the exact line count: it is read back once (any input, however
+        // short its lines, fits), where the asynchronous form takes the caller's bound
         StageTimer t(c, st, HHGT_STAGE_INDEX);
-        TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, cnt, st));
-        TRY(launch_scan_exclusive_u32(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), n_regions,
-                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
-        // line count back to the host: sizes every later launch
+        TRY(encode_stage_index(c, text, nbytes, n_regions, cnt, st));
         c->h_counters->n_lines = 0;
         c->h_counters->err_density = 0;
         HIP_TRY(hipMemcpyAsync(&c->h_counters->n_lines, c->prefix.as<uint32_t>() + n_regions, 4,
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&c->h_counters->err_density, &cnt->err_density, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        t.stop();
         n_lines = (uint32_t)(c->h_counters->n_lines & 0xFFFFFFFFull);
         if (c->h_counters->err_density) {
             hhgt_set_error("encode: more than %u newlines inside one %u-byte region (not VCF text)", INDEX_CAP,
                            INDEX_REGION);
             return HHGT_ERR_LINE_DENSITY;
         }
-        TRY(c->nl.ensure(((size_t)n_lines + 1) * 4));
-        TRY(c->scan_tmp.ensure(scan_tmp_elems(n_lines) * 4));
-        TRY(launch_compact_newlines(c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(),
-                                    n_regions, c->nl.as<uint32_t>(), st));
-        t.stop();
     }
     if (stats) stats->n_lines = n_lines;
     if (n_lines == 0) return HHGT_OK;
-
-    // ---- stage: fixed columns, filter, kept-record compaction
-    const size_t nl4 = ((size_t)n_lines + 1) * 4;
-    DevBuf *per_line[] = {&c->l_soff, &c->l_lend, &c->l_pos, &c->l_refalt, &c->l_flags, &c->l_keep,
-                          &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff, &c->k_lend, &c->k_meta,
-                          &c->redo_list, &c->redo_flag};
-    for (DevBuf *b : per_line) TRY(b->ensure(nl4));
-    TRY(c->run_first.ensure(MAX_CHROM_RUNS * 8));
-    TRY(c->run_off.ensure(MAX_CHROM_RUNS * 4));
-    {
-        StageTimer t(c, st, HHGT_STAGE_FIXED);
-        TRY(launch_parse_fixed(text, nbytes, c->nl.as<uint32_t>(), n_lines, c->region.as<RegionFilter>(), L.S,
-                               c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(),
-                               c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(), c->l_keep.as<uint32_t>(),
-                               c->l_cnew.as<uint32_t>(), cnt, st));
-        TRY(launch_scan_exclusive_u32(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), n_lines,
-                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
-        TRY(launch_scan_exclusive_u32(c->l_cnew.as<uint32_t>(), c->l_crun.as<uint32_t>(), n_lines,
-                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
-        HIP_TRY(hipMemsetAsync(c->redo_flag.p, 0, (size_t)n_lines * 4, st));
-        TRY(launch_compact_kept(c->nl.as<uint32_t>(), n_lines, c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(),
-                                c->l_pos.as<uint32_t>(), c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(),
-                                c->l_kidx.as<uint32_t>(), c->l_crun.as<uint32_t>(), c->k_soff.as<uint32_t>(),
-                                c->k_lend.as<uint32_t>(), c->k_meta.as<uint32_t>(), c->redo_list.as<uint32_t>(),
-                                c->run_first.as<uint64_t>(), c->run_off.as<uint32_t>(), MAX_CHROM_RUNS, v_base,
-                                L.v_capacity, d_start, d_stop, d_ref, d_alt, cnt, st));
-        t.stop();
-    }
-    // ---- stage: GT tiles (fixed-width lines)
-    if (L.S > 0) {
-        StageTimer t(c, st, HHGT_STAGE_ENCODE);
-        TRY(launch_encode_tiles(text, nbytes, c->k_soff.as<uint32_t>(), c->k_meta.as<uint32_t>(), n_lines, v_base,
-                                L, static_cast<int8_t *>(d_G), c->redo_list.as<uint32_t>(),
-                                c->redo_flag.as<uint32_t>(), cnt, st));
-        t.stop();
-        StageTimer t2(c, st, HHGT_STAGE_GENERAL);
-        TRY(launch_encode_general(text, nbytes, c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(),
-                                  c->k_meta.as<uint32_t>(), c->redo_list.as<uint32_t>(), v_base, L,
-                                  static_cast<int8_t *>(d_G), cnt, c->prop.multiProcessorCount, st));
-        t2.stop();
-    }
-    HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    TRY(encode_stage_rest(c, text, nbytes, n_regions, n_lines, rf, L, c->cursor.as<uint64_t>(), d_G, d_start, d_stop, d_ref,
+                          d_alt, cnt, st));
+    TRY(encode_finish(c, c->cursor.as<uint64_t>(), L, cnt, st));
+    hhgt_encode_result *hr = &c->h_result;
+    hr->done = 0u;
+    HIP_TRY(hipMemcpyAsync(c->h_result_pinned, c->result.p, sizeof(hhgt_encode_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const DevCounters &h = *c->h_counters;
-    if (stats) {
-        stats->n_lines = n_lines;
-        stats->n_records = h.n_records;
-        stats->n_kept = h.n_kept;
-        stats->n_drop_region = h.n_drop_region;
-        stats->n_drop_filter = h.n_drop_filter;
-        stats->n_haploid_padded = h.n_haploid;
-        stats->n_malformed = h.n_malformed;
-        stats->n_general_lines = h.n_general;
-        stats->n_chrom_runs = h.n_chrom_runs;
-    }
-    if (h.n_malformed) {
-        hhgt_set_error("Error parsing VCF file: %llu malformed record(s) (too few columns, bad POS, FORMAT without GT)",
-                       (unsigned long long)h.n_malformed);
-        return HHGT_ERR_MALFORMED;
-    }
-    if (v_base + h.n_kept > L.v_capacity) {
-        hhgt_set_error("encode: %llu kept records at v_base %llu exceed v_capacity %llu",
-                       (unsigned long long)h.n_kept, (unsigned long long)v_base, (unsigned long long)L.v_capacity);
-        return HHGT_ERR_CAPACITY;
-    }
-    if (h.n_chrom_runs > MAX_CHROM_RUNS) {
-        hhgt_set_error("encode: %llu CHROM runs in one text block (limit %u): the input is not sorted by contig",
-                       (unsigned long long)h.n_chrom_runs, MAX_CHROM_RUNS);
-        return HHGT_ERR_CAPACITY;
-    }
-    // CHROM runs (names are a few bytes each; read back lazily but while the text is still resident)
-    uint32_t n_runs = (uint32_t)h.n_chrom_runs;
+    *hr = *c->h_result_pinned;
+    if (stats) *stats = hr->stats;
+    TRY(hhgt_encode_result_status(hr));
+    // CHROM runs: names were copied out of the text by the compaction kernel
+    const uint32_t n_runs = (uint32_t)hr->stats.n_chrom_runs;
     if (n_runs) {
         std::vector<uint64_t> first(n_runs);
-        std::vector<uint32_t> off(n_runs);
-        HIP_TRY(hipMemcpy(first.data(), c->run_first.p, n_runs * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(off.data(), c->run_off.p, n_runs * 4, hipMemcpyDeviceToHost));
+        std::vector<char> names((size_t)n_runs * 32);
+        if (n_runs <= HHGT_RESULT_RUNS) {
+            memcpy(first.data(), hr->run_first, n_runs * 8);
+            memcpy(names.data(), hr->run_names, (size_t)n_runs * 32);
+        } else {
+            HIP_TRY(hipMemcpy(first.data(), c->run_first.p, (size_t)n_runs * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(names.data(), c->run_names.p, (size_t)n_runs * 32, hipMemcpyDeviceToHost));
+        }
         for (uint32_t r = 0; r < n_runs; ++r) {
-            char buf[64];
-            size_t take = nbytes - off[r] < 63 ? (size_t)(nbytes - off[r]) : 63;
-            HIP_TRY(hipMemcpy(buf, text + off[r], take, hipMemcpyDeviceToHost));
-            size_t l = 0;
-            while (l < take && buf[l] != '\t' && buf[l] != '\n') ++l;
             c->run_first_kept.push_back(first[r]);
-            c->run_names.emplace_back(buf, l);
+            c->run_names_host.emplace_back(names.data() + (size_t)r * 32, strnlen(names.data() + (size_t)r * 32, 31));
         }
     }
     return HHGT_OK;
@@ -433,8 +578,8 @@ extern "C" int hhgt_encode_chrom_runs(hhgt_ctx *c, uint32_t max_runs, uint64_t *
         if (first_kept) first_kept[r] = c->run_first_kept[r];
         if (names) {
             memset(names + (size_t)r * 32, 0, 32);
-            size_t l = c->run_names[r].size() < 31 ? c->run_names[r].size() : 31;
-            memcpy(names + (size_t)r * 32, c->run_names[r].data(), l);
+            size_t l = c->run_names_host[r].size() < 31 ? c->run_names_host[r].size() : 31;
+            memcpy(names + (size_t)r * 32, c->run_names_host[r].data(), l);
         }
     }
     return HHGT_OK;
@@ -453,6 +598,15 @@ extern "C" int hhgt_pad_tail(hhgt_ctx *c, const hhgt_layout *lay, uint64_t v_end
     }
     return launch_pad_tail(L, v_end, vcol_begin, vcol_end, static_cast<int8_t *>(d_G),
                            reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int hhgt_pad_tail_cursor(hhgt_ctx *c, const hhgt_layout *lay, const uint64_t *d_cursor, void *d_G, void *stream)
+{
+    if (!c || !d_G || !d_cursor) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    LayoutDev L;
+    TRY(make_layout(lay, &L));
+    return launch_pad_tail_cursor(L, d_cursor, static_cast<int8_t *>(d_G), reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- compress -------------------------------------------------------------------------------------
@@ -505,6 +659,12 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
     TRY(check_codec_args(chunk_nbytes, typesize, blocksize, format));
     if (total_bytes) *total_bytes = 0;
     if (n_chunks == 0) return HHGT_OK;
+    if (!total_bytes && dst_cap < n_chunks * (chunk_nbytes + 32)) {
+        // without the read-back an overflow could not be reported: chunks that do not fit would silently be missing
+        hhgt_set_error("compress: the asynchronous form (total_bytes == NULL) needs dst_cap >= hhgt_compress_bound() = %llu, got %llu",
+                       (unsigned long long)(n_chunks * (chunk_nbytes + 32)), (unsigned long long)dst_cap);
+        return HHGT_ERR_CAPACITY;
+    }
     blocksize = effective_blocksize(chunk_nbytes, typesize, blocksize);
     uint32_t nblocks, nwaves;
     size_t slot;

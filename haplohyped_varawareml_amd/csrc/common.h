@@ -44,8 +44,12 @@ struct DevCounters {
     unsigned long long n_general;    // entries in the redo (variable-width) list
     unsigned long long n_chrom_runs;
     unsigned long long err_density;  // newline-slot overflow
-    unsigned long long pad[6];
+    unsigned long long err_lines;    // lines beyond the caller's max_lines (asynchronous form only)
+    unsigned long long cursor_after; // *d_cursor after the call
+    unsigned long long pad[4];
 };
+
+#define MAX_CHROM_RUNS 4096u
 
 struct RegionFilter {
     char contig[64];
@@ -69,6 +73,8 @@ struct LayoutDev {
     uint32_t Sc;         // samples per chunk (dense: S)
     uint64_t Vc;         // variants per chunk (dense: v_capacity)
     uint64_t v_capacity;
+    uint32_t ring;       // > 0: G is a ring of `ring` chunk columns (v_capacity = ring * Vc), kept indices unbounded
+    uint32_t pad_;
 };
 
 // workspace buffer that only grows
@@ -86,17 +92,20 @@ struct hhgt_ctx {
     // index / fixed / keep workspaces
     DevBuf slots, counts, prefix, nl, scan_tmp;
     DevBuf l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_kidx, l_cnew, l_crun;
-    DevBuf k_soff, k_lend, k_meta, redo_list, redo_flag, run_first, run_off;
+    DevBuf k_soff, k_lend, k_meta, redo_list, redo_flag, run_first, run_names;
     DevBuf counters;       // DevCounters
-    DevBuf region;         // RegionFilter
+    DevBuf cursor;         // uint64: v_base of the synchronous hhgt_encode_text (the asynchronous form gets the caller's)
+    DevBuf result;         // hhgt_encode_result staging of the asynchronous form
     // compress workspaces
     DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut, crc_x2n;
     bool crc_x2n_ready = false;
     // pinned host mirror for counters
     DevCounters *h_counters = nullptr;
+    hhgt_encode_result *h_result_pinned = nullptr;
+    hhgt_encode_result h_result;
     // last encode's chrom runs (host)
     std::vector<uint64_t> run_first_kept;
-    std::vector<std::string> run_names;
+    std::vector<std::string> run_names_host;
     int clevel = 5;        // Blosc clevel analogue (reference: compression_opts[4] = 5)
     // profiling
     int profiling = 0;
@@ -127,28 +136,34 @@ size_t scan_tmp_elems(uint64_t n);
 // index.hip
 int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
                           uint32_t n_regions, DevCounters *d_cnt, hipStream_t st);
+// Everything after the newline index is sized by a host-side BOUND on the line count (max_lines) and reads the
+// actual count (d_nlines = prefix[n_regions]) and the append position (d_cursor) from device memory, so the chain
+// can be queued without a host round trip (hhgt_encode_text_async).
 int launch_compact_newlines(const uint32_t *d_slots, const uint32_t *d_counts, const uint32_t *d_prefix,
-                            uint32_t n_regions, uint32_t *d_nl, hipStream_t st);
-int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, uint32_t n_lines,
-                       const RegionFilter *d_region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
+                            uint32_t n_regions, uint32_t *d_nl, uint32_t max_lines, hipStream_t st);
+int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines,
+                       uint32_t max_lines, const RegionFilter &region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
                        uint32_t *l_pos, uint32_t *l_refalt, uint32_t *l_flags, uint32_t *l_keep,
                        uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st);
-int launch_compact_kept(const uint32_t *d_nl, uint32_t n_lines, const uint32_t *l_soff, const uint32_t *l_lend,
+int launch_compact_kept(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines, uint32_t max_lines,
+                        const uint32_t *l_soff, const uint32_t *l_lend,
                         const uint32_t *l_pos, const uint32_t *l_refalt, const uint32_t *l_flags,
                         const uint32_t *l_kidx, const uint32_t *l_crun, uint32_t *k_soff, uint32_t *k_lend,
-                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint32_t *run_off,
-                        uint32_t max_runs, uint64_t v_base, uint64_t v_capacity, uint32_t *d_start,
+                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint8_t *run_names,
+                        uint32_t max_runs, const uint64_t *d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *d_start,
                         uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, hipStream_t st);
 
 // encode.hip
 int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_meta,
-                        uint32_t n_lines_bound, uint64_t v_base, LayoutDev lay, int8_t *d_G,
+                        uint32_t n_lines_bound, const uint64_t *d_cursor, LayoutDev lay, int8_t *d_G,
                         uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st);
 int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_lend,
-                          const uint32_t *k_meta, const uint32_t *redo_list, uint64_t v_base, LayoutDev lay,
+                          const uint32_t *k_meta, const uint32_t *redo_list, const uint64_t *d_cursor, LayoutDev lay,
                           int8_t *d_G, DevCounters *d_cnt, int n_cu, hipStream_t st);
 int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, int8_t *d_G,
                     hipStream_t st);
+// zero [*d_cursor, round_up(*d_cursor, Vc)) of the cursor's chunk column and the sample padding rows of that column
+int launch_pad_tail_cursor(LayoutDev lay, const uint64_t *d_cursor, int8_t *d_G, hipStream_t st);
 
 // lz4.hip
 size_t lz4_slot_bytes(int neblock);
@@ -171,6 +186,7 @@ void crc32_x2n_table(uint32_t *t /*[32]*/);
 static inline __host__ __device__ uint64_t layout_offset(const LayoutDev &L, uint32_t s, uint64_t v)
 {
     uint64_t vcol = v / L.Vc, vin = v - vcol * L.Vc;
+    if (L.ring) vcol %= L.ring;
     uint32_t scol = (L.sc_log2 >= 31) ? 0u : (s >> L.sc_log2);
     uint32_t sin = s - scol * L.Sc;
     return (((vcol * L.n_sc + scol) * L.Sc + sin) * L.Vc + vin) * 2ull;

@@ -51,9 +51,10 @@ typedef uint32_t u32x4_al __attribute__((ext_vector_type(4)));
 template <int TV>
 __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
     const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ k_soff,
-    const uint32_t *__restrict__ k_meta, uint64_t v_base, LayoutDev lay, int8_t *__restrict__ G,
+    const uint32_t *__restrict__ k_meta, const uint64_t *__restrict__ d_cursor, LayoutDev lay, int8_t *__restrict__ G,
     uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag, DevCounters *cnt)
 {
+    const uint64_t v_base = *d_cursor;   // append position: device-resident, so a chain of calls needs no host round trip
     constexpr int LW = TV / 4;        // lines per wave
     constexpr int SLOTS = TV / 8;     // 16-byte slots per LDS row
     constexpr int WSL = SLOTS / 4;    // slots per row owned by one wave
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
     const uint32_t n_kept = (uint32_t)cnt->n_kept;
     const uint64_t gv0 = (v_base / TV + blockIdx.x) * (uint64_t)TV;  // first global column of tile
     const long long k0 = (long long)gv0 - (long long)v_base;         // batch-local kept index of it
-    if (k0 >= (long long)n_kept || gv0 >= lay.v_capacity) return;
+    if (k0 >= (long long)n_kept || (!lay.ring && gv0 >= lay.v_capacity)) return;
     const uint32_t s0 = blockIdx.y * TILE_S;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
     __syncthreads();
     // LDS -> HBM: each row leaves as one contiguous 2*TV-byte run (SLOTS lanes x 16 B)
     const uint32_t c16 = threadIdx.x & (SLOTS - 1);
-    const uint64_t vcol = gv0 / lay.Vc, vin = gv0 - vcol * lay.Vc;
+    uint64_t vcol = gv0 / lay.Vc;
+    const uint64_t vin = gv0 - vcol * lay.Vc;
+    if (lay.ring) vcol %= lay.ring;
     const long long kfirst = k0 + (long long)c16 * 8;  // batch-local kept index of this lane's 8 columns
     constexpr int ROWS_PER_IT = 256 / SLOTS;
 #pragma unroll 4
@@ -228,9 +231,11 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                                                         const uint32_t *__restrict__ k_soff,
                                                         const uint32_t *__restrict__ k_lend,
                                                         const uint32_t *__restrict__ k_meta,
-                                                        const uint32_t *__restrict__ redo_list, uint64_t v_base,
+                                                        const uint32_t *__restrict__ redo_list,
+                                                        const uint64_t *__restrict__ d_cursor,
                                                         LayoutDev lay, int8_t *__restrict__ G, DevCounters *cnt)
 {
+    const uint64_t v_base = *d_cursor;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * 4u;
@@ -245,8 +250,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         const uint32_t k = redo_list[idx];
         const uint32_t soff = k_soff[k], lend = k_lend[k], gtidx = k_meta[k] >> 8;
         const uint64_t v = v_base + k;
-        if (v >= lay.v_capacity) continue;
-        const uint64_t vcol = v / lay.Vc, vin = v - vcol * lay.Vc;
+        if (!lay.ring && v >= lay.v_capacity) continue;
+        uint64_t vcol = v / lay.Vc;
+        const uint64_t vin = v - vcol * lay.Vc;
+        if (lay.ring) vcol %= lay.ring;
         const uint32_t rs = soff - 1u;  // the 9th tab: every sample field is preceded by a tab in [rs, lend)
         uint32_t tabs_before = 0;
         for (uint32_t base = rs; base < lend; base += 1024u) {
@@ -359,34 +366,71 @@ __global__ __launch_bounds__(256) void k_zero_rect(LayoutDev lay, uint64_t vcol0
     }
 }
 
+// cursor form of the tail padding: the kept count lives in device memory (asynchronous chains)
+__global__ __launch_bounds__(256) void k_zero_tail_cursor(LayoutDev lay, const uint64_t *__restrict__ d_cursor,
+                                                          int8_t *__restrict__ G)
+{
+    const uint64_t v_end = *d_cursor;
+    uint64_t vcol = v_end / lay.Vc;
+    const uint64_t c0 = v_end - vcol * lay.Vc;
+    if (c0 == 0) return;                       // the cursor sits on a column boundary: nothing is open
+    if (lay.ring) vcol %= lay.ring;
+    const uint32_t r = blockIdx.y;             // padded sample row
+    const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (r >> lay.sc_log2);
+    const uint32_t sin = r - scol * lay.Sc;
+    int8_t *row = G + (((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc) * 2ull;
+    const uint64_t b0 = r < lay.S ? c0 * 2ull : 0ull, b1 = lay.Vc * 2ull;   // sample padding rows: the whole row
+    const uint64_t seg0 = b0 / 16ull, seg1 = (b1 + 15ull) / 16ull;
+    for (uint64_t sgm = seg0 + blockIdx.x * blockDim.x + threadIdx.x; sgm < seg1; sgm += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = sgm * 16ull, hi = lo + 16ull;
+        if (lo >= b0 && hi <= b1)
+            *reinterpret_cast<uint4 *>(row + lo) = make_uint4(0, 0, 0, 0);
+        else
+            for (uint64_t b = lo < b0 ? b0 : lo; b < (hi > b1 ? b1 : hi); ++b) row[b] = 0;
+    }
+}
+
+int launch_pad_tail_cursor(LayoutDev lay, const uint64_t *d_cursor, int8_t *d_G, hipStream_t st)
+{
+    const uint32_t S_pad = lay.n_sc * lay.Sc;
+    if (S_pad == 0) return HHGT_OK;
+    uint64_t segs = (lay.Vc * 2 + 15) / 16 + 1;
+    uint32_t gx = (uint32_t)((segs + 255) / 256);
+    if (gx > 8) gx = 8;
+    hipLaunchKernelGGL(k_zero_tail_cursor, dim3(gx, S_pad), dim3(256), 0, st, lay, d_cursor, d_G);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_meta,
-                        uint32_t n_lines_bound, uint64_t v_base, LayoutDev lay, int8_t *d_G,
+                        uint32_t n_lines_bound, const uint64_t *d_cursor, LayoutDev lay, int8_t *d_G,
                         uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st)
 {
     if (n_lines_bound == 0 || lay.S == 0) return HHGT_OK;
     static const int tv = getenv("HHGT_TILE_V") ? atoi(getenv("HHGT_TILE_V")) : 64;
     uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
     if (tv == 128) {
-        uint64_t tiles_v = ((v_base % 128) + n_lines_bound + 127) / 128;
+        // the append position is only known on the device: one tile more than the lines need covers any phase
+        uint64_t tiles_v = (127 + (uint64_t)n_lines_bound + 127) / 128;
         hipLaunchKernelGGL(k_encode_tiles<128>, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
-                           k_meta, v_base, lay, d_G, redo_list, redo_flag, d_cnt);
+                           k_meta, d_cursor, lay, d_G, redo_list, redo_flag, d_cnt);
     } else {
-        uint64_t tiles_v = ((v_base % 64) + n_lines_bound + 63) / 64;
+        uint64_t tiles_v = (63 + (uint64_t)n_lines_bound + 63) / 64;
         hipLaunchKernelGGL(k_encode_tiles<64>, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
-                           k_meta, v_base, lay, d_G, redo_list, redo_flag, d_cnt);
+                           k_meta, d_cursor, lay, d_G, redo_list, redo_flag, d_cnt);
     }
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
 
 int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_lend,
-                          const uint32_t *k_meta, const uint32_t *redo_list, uint64_t v_base, LayoutDev lay,
+                          const uint32_t *k_meta, const uint32_t *redo_list, const uint64_t *d_cursor, LayoutDev lay,
                           int8_t *d_G, DevCounters *d_cnt, int n_cu, hipStream_t st)
 {
     if (lay.S == 0) return HHGT_OK;
     hipLaunchKernelGGL(k_encode_general, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
-                       k_meta, redo_list, v_base, lay, d_G, d_cnt);
+                       k_meta, redo_list, d_cursor, lay, d_G, d_cnt);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

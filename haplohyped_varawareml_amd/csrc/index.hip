@@ -94,20 +94,21 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
 __global__ __launch_bounds__(256) void k_compact_newlines(const uint32_t *__restrict__ slots,
                                                           const uint32_t *__restrict__ counts,
                                                           const uint32_t *__restrict__ prefix,
-                                                          uint32_t n_regions, uint32_t *__restrict__ nl)
+                                                          uint32_t n_regions, uint32_t *__restrict__ nl,
+                                                          uint32_t max_lines)
 {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
     uint32_t c = counts[r], p = prefix[r];
     const uint32_t *my = slots + (size_t)r * INDEX_CAP;
-    for (uint32_t k = 0; k < c; ++k) nl[p + k] = my[k];
+    for (uint32_t k = 0; k < c && p + k < max_lines; ++k) nl[p + k] = my[k];   // lines past the caller's bound: err_lines
 }
 
 // ---------------------------------------------------------------------------------------------
 // fixed columns: one lane per line
 __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__ text, uint64_t n,
-                                                     const uint32_t *__restrict__ nl, uint32_t n_lines,
-                                                     const RegionFilter *__restrict__ rf, uint32_t S,
+                                                     const uint32_t *__restrict__ nl, const uint32_t *__restrict__ d_nlines,
+                                                     uint32_t max_lines, const RegionFilter rfv, uint32_t S,
                                                      uint32_t *__restrict__ l_soff, uint32_t *__restrict__ l_lend,
                                                      uint32_t *__restrict__ l_pos, uint32_t *__restrict__ l_refalt,
                                                      uint32_t *__restrict__ l_flags, uint32_t *__restrict__ l_keep,
@@ -119,7 +120,19 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
     // independent 16-byte loads per lane and parked in LDS (row stride 17 dwords: conflict-free byte reads);
     // rd() serves the walk from there and falls back to global memory past byte 64.
     __shared__ uint32_t stage[256][17];
+    const RegionFilter *rf = &rfv;   // by value in the kernel arguments: no upload, nothing to keep alive on the host
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_found = *d_nlines;
+    const uint32_t n_lines = n_found < max_lines ? n_found : max_lines;
+    if (i == 0) {
+        cnt->n_lines = n_found;
+        cnt->err_lines = n_found > max_lines ? (unsigned long long)(n_found - max_lines) : 0ull;
+    }
+    if (blockIdx.x * blockDim.x >= n_lines) {
+        // the grid is sized by max_lines: the scans behind this kernel run over max_lines flags
+        if (i < max_lines) l_keep[i] = l_cnew[i] = 0u;
+        return;
+    }
     uint32_t flags = 0;
     uint32_t s = 0, e = 0;
     bool staged = false;
@@ -259,6 +272,8 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
         l_flags[i] = flags;
         l_keep[i] = (flags & LF_KEEP) ? 1u : 0u;
         l_cnew[i] = (flags & LF_CHROM_NEW) ? 1u : 0u;
+    } else if (i < max_lines) {
+        l_keep[i] = l_cnew[i] = 0u;
     }
     // statistics: one atomic per wave per category
     const uint32_t lane = threadIdx.x & 63u;
@@ -275,24 +290,37 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
 
 // one thread per line; kept lines scatter to their compacted slot
 __global__ __launch_bounds__(256) void k_compact_kept(
-    const uint32_t *__restrict__ nl, uint32_t n_lines, const uint32_t *__restrict__ l_soff,
+    const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ nl, const uint32_t *__restrict__ d_nlines,
+    uint32_t max_lines, const uint32_t *__restrict__ l_soff,
     const uint32_t *__restrict__ l_lend, const uint32_t *__restrict__ l_pos, const uint32_t *__restrict__ l_refalt,
     const uint32_t *__restrict__ l_flags, const uint32_t *__restrict__ l_kidx, const uint32_t *__restrict__ l_crun,
     uint32_t *__restrict__ k_soff, uint32_t *__restrict__ k_lend, uint32_t *__restrict__ k_meta,
-    uint32_t *__restrict__ redo_list, uint64_t *__restrict__ run_first, uint32_t *__restrict__ run_off,
-    uint32_t max_runs, uint64_t v_base, uint64_t v_capacity, uint32_t *__restrict__ d_start,
+    uint32_t *__restrict__ redo_list, uint64_t *__restrict__ run_first, uint8_t *__restrict__ run_names,
+    uint32_t max_runs, const uint64_t *__restrict__ d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *__restrict__ d_start,
     uint32_t *__restrict__ d_stop, uint8_t *__restrict__ d_ref, uint8_t *__restrict__ d_alt, DevCounters *cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_found = *d_nlines;
+    const uint32_t n_lines = n_found < max_lines ? n_found : max_lines;
     if (i >= n_lines) return;
+    const uint64_t v_base = *d_cursor;
     const uint32_t flags = l_flags[i];
     if (flags & LF_CHROM_NEW) {
         // run id = number of CHROM_NEW flags before this line; the run's first kept index is the
-        // exclusive kept-prefix here; its name is the CHROM field at the start of this line
+        // exclusive kept-prefix here; its name is the CHROM field at the start of this line (copied out now: the text
+        // buffer may be recycled before the host looks at the runs)
         uint32_t rid = l_crun[i];
         if (rid < max_runs) {
             run_first[rid] = l_kidx[i];
-            run_off[rid] = i ? nl[i - 1] + 1u : 0u;
+            const uint32_t s0 = i ? nl[i - 1] + 1u : 0u;
+            uint8_t *nm = run_names + (size_t)rid * 32u;
+            uint32_t q = 0;
+            for (; q < 31u && (uint64_t)s0 + q < n; ++q) {
+                const uint8_t ch = text[s0 + q];
+                if (ch == '\t' || ch == '\n') break;
+                nm[q] = ch;
+            }
+            for (; q < 32u; ++q) nm[q] = 0;
         }
     }
     if (i == n_lines - 1) {
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     }
     if (!(flags & LF_KEEP)) return;
     const uint32_t k = l_kidx[i];
-    const uint64_t v = v_base + k;
+    uint64_t v = v_base + k;
     const uint32_t ra = l_refalt[i];
     k_soff[k] = l_soff[i];
     k_lend[k] = l_lend[i];
@@ -310,6 +338,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
         unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
         redo_list[slot] = k;
     }
+    if (ring) v %= v_capacity;   // ring of chunk columns: the tables wrap with it
     if (v < v_capacity) {
         uint32_t pos0 = l_pos[i];
         if (d_start) d_start[v] = pos0;
@@ -330,37 +359,38 @@ int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, 
 }
 
 int launch_compact_newlines(const uint32_t *d_slots, const uint32_t *d_counts, const uint32_t *d_prefix,
-                            uint32_t n_regions, uint32_t *d_nl, hipStream_t st)
+                            uint32_t n_regions, uint32_t *d_nl, uint32_t max_lines, hipStream_t st)
 {
     hipLaunchKernelGGL(k_compact_newlines, dim3((n_regions + 255) / 256), dim3(256), 0, st, d_slots, d_counts,
-                       d_prefix, n_regions, d_nl);
+                       d_prefix, n_regions, d_nl, max_lines);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
 
-int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, uint32_t n_lines,
-                       const RegionFilter *d_region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
+int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines,
+                       uint32_t max_lines, const RegionFilter &region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
                        uint32_t *l_pos, uint32_t *l_refalt, uint32_t *l_flags, uint32_t *l_keep,
                        uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st)
 {
-    if (n_lines == 0) return HHGT_OK;
-    hipLaunchKernelGGL(k_parse_fixed, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, n_lines,
-                       d_region, S, l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_cnew, d_cnt);
+    if (max_lines == 0) return HHGT_OK;
+    hipLaunchKernelGGL(k_parse_fixed, dim3((max_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, d_nlines,
+                       max_lines, region, S, l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_cnew, d_cnt);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
 
-int launch_compact_kept(const uint32_t *d_nl, uint32_t n_lines, const uint32_t *l_soff, const uint32_t *l_lend,
+int launch_compact_kept(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines, uint32_t max_lines,
+                        const uint32_t *l_soff, const uint32_t *l_lend,
                         const uint32_t *l_pos, const uint32_t *l_refalt, const uint32_t *l_flags,
                         const uint32_t *l_kidx, const uint32_t *l_crun, uint32_t *k_soff, uint32_t *k_lend,
-                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint32_t *run_off,
-                        uint32_t max_runs, uint64_t v_base, uint64_t v_capacity, uint32_t *d_start,
+                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint8_t *run_names,
+                        uint32_t max_runs, const uint64_t *d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *d_start,
                         uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, hipStream_t st)
 {
-    if (n_lines == 0) return HHGT_OK;
-    hipLaunchKernelGGL(k_compact_kept, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_nl, n_lines, l_soff,
-                       l_lend, l_pos, l_refalt, l_flags, l_kidx, l_crun, k_soff, k_lend, k_meta, redo_list,
-                       run_first, run_off, max_runs, v_base, v_capacity, d_start, d_stop, d_ref, d_alt, d_cnt);
+    if (max_lines == 0) return HHGT_OK;
+    hipLaunchKernelGGL(k_compact_kept, dim3((max_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, d_nlines, max_lines,
+                       l_soff, l_lend, l_pos, l_refalt, l_flags, l_kidx, l_crun, k_soff, k_lend, k_meta, redo_list,
+                       run_first, run_names, max_runs, d_cursor, v_capacity, ring, d_start, d_stop, d_ref, d_alt, d_cnt);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

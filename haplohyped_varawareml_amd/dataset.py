@@ -44,15 +44,14 @@ def calculate_midpoint_region(start, end, seq_length):
 
 
 def parse_encode_dict(encode_spec):
-    """common_utils.py:62-79"""
-    if not encode_spec:
-        return {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
-    elif isinstance(encode_spec, (list, tuple, str)):
-        return {base: i for i, base in enumerate(encode_spec)}
-    elif isinstance(encode_spec, dict):
+    """base -> channel map with the behaviour of common_utils.py:62-79: nothing given = A,C,G,T,N in that order; a
+    sequence (list, tuple or string) numbers its bases in order; a dict passes through; anything else is a TypeError
+    with the reference's message"""
+    if isinstance(encode_spec, dict) and encode_spec:
         return encode_spec
-    else:
-        raise TypeError("Please input as dict, list or string!")
+    if isinstance(encode_spec, (str, list, tuple)) or not encode_spec:
+        return dict(zip(encode_spec or "ACGTN", range(len(encode_spec or "ACGTN"))))
+    raise TypeError("Please input as dict, list or string!")
 
 
 def channel_lut(encode_spec):

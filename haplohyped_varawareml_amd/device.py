@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BLOSC1, BLOSC2, EncodeStats, HhgtError, Layout, check
+from ._lib import BLOSC1, BLOSC2, EncodeResultRec, EncodeStats, HhgtError, Layout, check
 
 # default on-disk geometry: one HDF5 chunk = 64 samples x 8192 variants x 2 haplotypes (1 MiB);
 # one Blosc2 block = half a sample row of the chunk = 4096 diploid calls (8 KiB -> two 4 KiB byte
@@ -17,6 +17,26 @@ DEFAULT_SC = 64
 DEFAULT_VC = 8192
 DEFAULT_TYPESIZE = 2
 DEFAULT_BLOCKSIZE = 8192
+
+
+def make_ring_layout(n_samples, ring_cols, sc=DEFAULT_SC, vc=DEFAULT_VC):
+    """ring of `ring_cols` chunk columns (streaming: kept indices wrap, see include/hhgt.h)"""
+    return Layout(int(n_samples), int(sc), int(vc), int(ring_cols), int(ring_cols) * int(vc))
+
+
+class PendingEncode:
+    """result record of one hhgt_encode_text_async call: pinned host memory the device writes when the call's work
+    has run.  .wait() synchronises on the event recorded behind the call and raises what the synchronous call would."""
+
+    def __init__(self):
+        self.buf = torch.zeros(C.sizeof(EncodeResultRec), dtype=torch.uint8).pin_memory()
+        self.rec = EncodeResultRec.from_address(self.buf.data_ptr())
+        self.event = torch.cuda.Event()
+
+    def wait(self):
+        self.event.synchronize()
+        check(_lib.load().hhgt_encode_result_status(C.c_void_p(self.buf.data_ptr())))
+        return self.rec
 
 
 def make_layout(n_samples, v_capacity, sc=DEFAULT_SC, vc=DEFAULT_VC):
@@ -147,6 +167,26 @@ class Context:
             out.n_kept = int(v_base) + int(st.n_kept)
             out.chrom_runs = self.chrom_runs()
         return out
+
+    def encode_text_async(self, text, n_samples, out, cursor, max_lines=None, region="", pending=None):
+        """hhgt_encode_text_async: appends at the device-resident `cursor` (int64 tensor [1]) into `out`'s buffers and
+        returns without waiting.  -> PendingEncode (call .wait() once the counts are needed)"""
+        assert text.is_cuda and text.dtype == torch.uint8 and text.is_contiguous()
+        nbytes = text.numel()
+        if max_lines is None:
+            max_lines = nbytes // (16 + 2 * max(n_samples, 0)) + 64
+        pending = pending or PendingEncode()
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_encode_text_async(self.h, _ptr(text), nbytes, (region or "").encode(),
+                                                  C.byref(out.layout), _ptr(cursor), int(max_lines), _ptr(out.G),
+                                                  _ptr(out.start), _ptr(out.stop), _ptr(out.ref), _ptr(out.alt),
+                                                  C.c_void_p(pending.buf.data_ptr()), _stream()))
+            pending.event.record(torch.cuda.current_stream())
+        return pending
+
+    def pad_tail_cursor(self, res, cursor):
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_pad_tail_cursor(self.h, C.byref(res.layout), _ptr(cursor), _ptr(res.G), _stream()))
 
     def chrom_runs(self):
         n = C.c_uint32(0)

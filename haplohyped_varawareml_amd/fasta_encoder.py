@@ -35,16 +35,13 @@ class ReferenceGenome:
 
     @staticmethod
     def parse_encode_list(encode_spec):
-        """fasta_encoder.py:32-45"""
-        if not encode_spec:
-            encode_spec = [b"A", b"C", b"G", b"T", b"N"]
-        elif isinstance(encode_spec, (list, tuple)):
-            encode_spec = [base.encode() if isinstance(base, str) else base for base in encode_spec]
-        elif isinstance(encode_spec, str):
-            encode_spec = [base.encode() for base in list(encode_spec)]
-        else:
+        """list of single-base byte strings, with the behaviour of fasta_encoder.py:32-45: nothing given = A,C,G,T,N;
+        a string is split into its characters; list / tuple items may be str or bytes; anything else is a TypeError
+        with the reference's message"""
+        spec = encode_spec or "ACGTN"
+        if not isinstance(spec, (str, list, tuple)):
             raise TypeError("Please input string or list of strings!")
-        return encode_spec
+        return [b.encode() if isinstance(b, str) else b for b in spec]
 
     # ---- helpers -----------------------------------------------------------------------------------
     def _context(self):

@@ -12,6 +12,7 @@ Differences by design: a missing tabix index is not an error (the reference asse
 haploid calls yield -9 for the second allele instead of tripping an assert (parse_vcf.cpp:46).
 """
 import os
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -19,17 +20,29 @@ import numpy as np
 _CACHE = OrderedDict()
 _CACHE_MAX = 2
 _ctx = None
+# The reference calls load_vcf from ThreadPoolExecutor workers (vcf_to_h5.py:191-192); its pybind11 binding holds
+# the GIL for the whole call, so those calls never overlap.  ctypes and torch release the GIL, and an hhgt context is
+# one-thread-at-a-time (include/hhgt.h), so the same serialisation is made explicit here: one lock around the cache
+# lookup, the device pass and the insert.  A second thread asking for the same (file, chromosome) waits and then
+# hits the cache instead of encoding the file again.
+_LOCK = threading.RLock()
 
 
 def _context():
     global _ctx
-    if _ctx is None:
-        from .device import Context
-        _ctx = Context(0)
-    return _ctx
+    with _LOCK:
+        if _ctx is None:
+            from .device import Context
+            _ctx = Context(0)
+        return _ctx
 
 
 def _encoded(in_vcf, chrom, sites_only):
+    with _LOCK:
+        return _encoded_locked(in_vcf, chrom, sites_only)
+
+
+def _encoded_locked(in_vcf, chrom, sites_only):
     from .pipeline import encode_file_resident
     st = os.stat(in_vcf)
     key = (os.path.abspath(in_vcf), st.st_mtime_ns, st.st_size, chrom or "", bool(sites_only))
@@ -61,7 +74,8 @@ class VCFLoader:
                 # cpp/vcfpp.h:373-377
                 raise RuntimeError("the 1-th sample are not in the VCF.\nparameter samples:" + str(sample))
             s = e["samples"].index(sample)
-            ph = e["G"][s].cpu().numpy()
+            with _LOCK:
+                ph = e["G"][s].cpu().numpy()
         except RuntimeError as ex:
             msg = str(ex)
             if not msg.startswith("Error parsing VCF file"):

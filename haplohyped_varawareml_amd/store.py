@@ -68,7 +68,8 @@ class StoreWriter:
             np.save(os.path.join(c["dir"], k + ".npy"), arr)
         json.dump(c["runs"], open(os.path.join(c["dir"], "chrom_runs.json"), "w"))
         S, sc, vc = len(self.meta["samples"]), self.meta["sc"], self.meta["vc"]
-        self.meta["groups"][c["name"]] = dict(n_variants=c["n_variants"], n_vcol=-(-max(c["n_variants"], 1) // vc),
+        # a file with no kept SNP gives a group with no chunk column
+        self.meta["groups"][c["name"]] = dict(n_variants=c["n_variants"], n_vcol=-(-c["n_variants"] // vc),
                                               n_scol=-(-max(S, 1) // sc), n_chunks=len(c["offsets"]) - 1,
                                               compressed_bytes=c["offsets"][-1], raw_bytes=c["raw_bytes"])
         self._cur = None
@@ -114,11 +115,17 @@ class GenotypeStore:
             if not info["filters"] or info["filters"][0][0] != FILTER_BLOSC:
                 raise ValueError(f"{path}:{name}/genotype is not a filter-32001 dataset")
             sc, vc = int(info["chunk_shape"][0]), int(info["chunk_shape"][1])
-            first = r.read_chunk(info, (0, 0, 0))
-            meta.update(sc=sc, vc=vc, typesize=int(first[3]), blocksize=int(first[8:12].view("<u4")[0]))
-            meta["groups"][name] = dict(n_variants=int(info["shape"][1]), n_vcol=-(-max(int(info["shape"][1]), 1) // vc),
+            # typesize from the filter's client data (h5file.blosc_cd_values); the Blosc block size only exists in the
+            # chunk headers, so it comes from the first group that has a chunk (a group without kept SNPs has none)
+            meta.update(sc=sc, vc=vc, typesize=int(info["filters"][0][1][2]))
+            meta.setdefault("blocksize", min(vc * 2, 8192))
+            if info["chunks"] and "_blocksize_seen" not in meta:
+                first = r.read_chunk(info, (0, 0, 0))
+                meta.update(blocksize=int(first[8:12].view("<u4")[0]), _blocksize_seen=True)
+            meta["groups"][name] = dict(n_variants=int(info["shape"][1]), n_vcol=-(-int(info["shape"][1]) // vc),
                                         n_scol=-(-max(len(samples), 1) // sc), n_chunks=len(info["chunks"]))
             self._h5_info[name] = info
+        meta.pop("_blocksize_seen", None)
         self.meta = meta
         self._h5 = r
 
@@ -166,6 +173,8 @@ class GenotypeStore:
         s = self._idx[sample] if isinstance(sample, str) else int(sample)
         sc, vc = self.meta["sc"], self.meta["vc"]
         scol, sin = divmod(s, sc)
+        if g["n_vcol"] == 0:
+            return np.zeros((0, 2), np.int8)
         parts = self._chunk_row(group, scol)
         rel = [0]
         for part in parts:

@@ -10,9 +10,10 @@
  *     isSNP filter vcfpp.h:990-1000)                                     pass -> int8 G[s, v', 2]
  *   VCFLoader::load_vcf_without_sample  cpp/parse_vcf.cpp:80-113        hhgt_encode_text with n_samples = 0
  *   h5py create_dataset(compression=32001,                              hhgt_compress_chunks (byte-shuffle + LZ4
- *     compression_opts=(2,2,0,0,5,1,2))  src/haplohyped/vcf_to_h5.py:134-135   -> Blosc2-framed chunks), and
- *     = hdf5plugin Blosc2 filter -> c-blosc2 shuffle + LZ4 block encode  hhgt_decompress_chunks (read side,
- *                                                                        src/utils/h5_reader.py:37-41)
+ *     compression_opts=(2,2,0,0,5,1,2))  src/haplohyped/vcf_to_h5.py:134-135   -> Blosc-framed chunks), and
+ *     = HDF5 filter 32001 = the Blosc (v1) filter of hdf5-blosc /       hhgt_decompress_chunks (read side,
+ *       hdf5plugin.Blosc: shuffle + LZ4-format blocks in Blosc-1         src/utils/h5_reader.py:37-41).  Both the
+ *       chunks (Blosc2's filter id is 32026)                Blosc-1 and the Blosc2 header are emitted.
  *   htslib bgzf_read_block + inflate under the reader                  hhgt_bgzf_scan + hhgt_inflate_members
  *     cpp/vcfpp.h:1381 (open), :1468 (record reads)                      (opt-in; the default keeps BGZF on the
  *                                                                        host: include/hhgt_reader.h)
@@ -71,7 +72,9 @@ typedef struct {
     int32_t n_samples;   /* S: number of sample columns in the VCF (0 = sites only)             */
     int32_t sc;          /* samples per chunk, 0 = dense                                        */
     int32_t vc;          /* variants per chunk, 0 = dense                                       */
-    int32_t reserved;
+    int32_t ring;        /* 0 = linear; > 0: G (and the per-record tables) are a RING of `ring` chunk
+                            columns, v_capacity == ring * vc, kept indices are unbounded and wrap
+                            (streaming ingest: completed columns leave while later text arrives)  */
     uint64_t v_capacity; /* kept-variant capacity of the G buffer                               */
 } hhgt_layout;
 
@@ -109,6 +112,39 @@ int hhgt_encode_text(hhgt_ctx *ctx, const void *d_text, uint64_t nbytes, const c
                      uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_stats *stats,
                      void *stream);
 
+/*
+ * Asynchronous form: nothing is read back, so a chain of calls (and what follows them on the stream) can be queued
+ * without the host waiting — the streaming ingest (hhgt_ingest.h) and bench.py's step are built on it.
+ *   d_cursor  : device uint64.  In: the global kept index the first kept record of this block gets (what v_base is
+ *               above).  Out: advanced by the number of kept records.  Chained calls append.
+ *   max_lines : caller's bound on the number of lines in the block (a VCF with S samples has at least 2*S + 16 bytes
+ *               per data line).  Sizes the workspaces and the grids; lines beyond it are not encoded and reported in
+ *               h_result->n_lines_over (hhgt_encode_result_status: HHGT_ERR_CAPACITY).
+ *   h_result  : PINNED host memory (hipHostMalloc / torch pin_memory), written by a copy queued on `stream` behind the
+ *               kernels; valid once the stream (or an event recorded after the call) has completed.  `done` is set
+ *               to 1 by that copy.  May be NULL.
+ * Errors that need the counts (malformed records, capacity, line density) are reported by hhgt_encode_result_status
+ * on the completed h_result, not by the call.
+ */
+#define HHGT_RESULT_RUNS 16
+typedef struct {
+    hhgt_encode_stats stats;
+    uint64_t cursor_before, cursor_after;
+    uint64_t n_lines_over;     /* lines beyond max_lines (not encoded)                                     */
+    uint64_t err_density;      /* newline-slot overflows (HHGT_ERR_LINE_DENSITY)                           */
+    uint64_t run_first[HHGT_RESULT_RUNS];   /* CHROM runs of the block: first kept index (block-local) ...  */
+    char run_names[HHGT_RESULT_RUNS][32];   /* ... and name; stats.n_chrom_runs may exceed HHGT_RESULT_RUNS */
+    uint64_t v_capacity;       /* of the layout the call was given (0 when it was a ring)                  */
+    uint32_t done, reserved;
+} hhgt_encode_result;
+
+int hhgt_encode_text_async(hhgt_ctx *ctx, const void *d_text, uint64_t nbytes, const char *region,
+                           const hhgt_layout *lay, uint64_t *d_cursor, uint32_t max_lines, void *d_G,
+                           uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt,
+                           hhgt_encode_result *h_result, void *stream);
+/* HHGT_OK, or the error the synchronous call would have returned (message via hhgt_last_error) */
+int hhgt_encode_result_status(const hhgt_encode_result *r);
+
 /* CHROM runs of the most recent hhgt_encode_text call (cpp/vcfpp.h:1076-1079 CHROM()):
  * run r covers kept indices [first_kept[r], first_kept[r+1]) (batch-local, i.e. without v_base)
  * and is named names[r*32 .. r*32+31] (NUL padded, truncated to 31 bytes). */
@@ -119,6 +155,9 @@ int hhgt_encode_chrom_runs(hhgt_ctx *ctx, uint32_t max_runs, uint64_t *first_kep
  * sample rows [S, round_up(S, sc)) of chunk columns [vcol_begin, vcol_end). */
 int hhgt_pad_tail(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_t vcol_begin,
                   uint64_t vcol_end, void *d_G, void *stream);
+/* The same for the chunk column that holds *d_cursor (device uint64, see hhgt_encode_text_async): variants
+ * [*d_cursor, round_up(*d_cursor, vc)) and the sample padding rows of that column.  No host round trip. */
+int hhgt_pad_tail_cursor(hhgt_ctx *ctx, const hhgt_layout *lay, const uint64_t *d_cursor, void *d_G, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Blosc2 chunk compress: byte-shuffle(typesize) + LZ4 block format, `blocksize`-byte blocks,
@@ -130,9 +169,8 @@ int hhgt_pad_tail(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_
  *                  [d_chunk_off[i], d_chunk_off[i+1])
  *   d_chunk_off  : device array of n_chunks + 1 uint64
  *   total_bytes  : host, optional; when non-NULL the call synchronises and returns the total (and
- *                  HHGT_ERR_CAPACITY if it exceeds dst_cap).  When NULL the call is asynchronous: chunks that would
- *                  not fit are not written, and the caller must check d_chunk_off[n_chunks] <= dst_cap itself
- *                  (dst_cap >= hhgt_compress_bound(...) always fits).
+ *                  HHGT_ERR_CAPACITY if it exceeds dst_cap).  When NULL the call is asynchronous and cannot report an
+ *                  overflow afterwards, so it REQUIRES dst_cap >= hhgt_compress_bound(...) (HHGT_ERR_CAPACITY otherwise).
  * Constraints: 1 <= typesize <= 255; blocksize % typesize == 0; 16 <= blocksize <= 65536 (clamped to the chunk size, as c-blosc does);
  * chunk_nbytes < 2 GiB.
  * The streams are valid LZ4 blocks for any input, but the match search is tuned to this path's data (byte planes of

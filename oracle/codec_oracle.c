@@ -4,10 +4,12 @@
  * Restates the codec the reference reaches through ONE call:
  *   create_dataset(..., compression=32001, compression_opts=(2,2,0,0,5,1,2), chunks=True)
  *   /root/reference/src/haplohyped/vcf_to_h5.py:134-135   (same opts: tests/test_compression.py:45-46,86)
- * i.e. HDF5 filter 32001 = hdf5plugin's Blosc2 filter -> c-blosc2: byte-shuffle (cd_values[5]=1),
- * clevel 5 (cd_values[4]), compcode 2 (cd_values[6]; LZ4HC in Blosc numbering, same block format
- * as LZ4).  hdf5plugin (>=4.0, bundles c-blosc2 2.x) and b2h5py are third-party, un-vendored and
- * unpinned (requirements.txt:7-8) and absent here, so their published formats are restated:
+ * Filter id 32001 is the registered id of the Blosc (v1) HDF5 filter — hdf5-blosc / hdf5plugin.Blosc; Blosc2's id
+ * is 32026 — although the reference's prose calls its codec "Blosc2" (DESIGN.md §4).  Its cd_values select
+ * byte-shuffle (cd_values[5]=1), clevel 5 (cd_values[4]), compcode 2 (cd_values[6]; LZ4HC in Blosc numbering, same
+ * block format as LZ4), and the stored chunks are Blosc-1 chunks (16-byte header).  hdf5plugin (>=4.0) and b2h5py
+ * are third-party, un-vendored and unpinned (requirements.txt:7-8) and absent here, so the published formats are
+ * restated — the Blosc-1 chunk, and the Blosc2 extended-header variant BASELINE.json's wording asks for:
  *   - LZ4 block format (lz4_Block_format.md): token | literal-length ext | literals | offset LE16 |
  *     match-length ext; last 5 bytes literal, last match starts >= 12 bytes before the end.
  *   - Blosc byte shuffle: dst[j*nelem + i] = src[i*typesize + j], tail (nbytes % typesize) verbatim.

@@ -30,29 +30,47 @@ def test_midpoint_region_and_lut():
     assert C4 == 4 and lut4[ord("N")] == 255 and lut4[ord("g")] == 2
 
 
-def numpy_expected(ds, items):
-    """documented semantics, one item at a time, plain numpy"""
-    L, C = ds.seq_length, ds.n_channels
+def independent_lut(spec):
+    """channel of every base byte, restated here from the documented rule (common_utils.py:62-103: channels in
+    the key order of the spec, default A,C,G,T,N; case-insensitive; anything else is N; a base without a channel
+    gives an all-zero row) — deliberately not the product's channel_lut"""
+    order = list(spec) if spec else ["A", "C", "G", "T", "N"]
+    chan = {b: i for i, b in enumerate(order)}
+    lut = np.full(256, chan.get("N", 255), np.uint8)
+    for b in "ACGT":
+        lut[ord(b)] = lut[ord(b.lower())] = chan.get(b, 255)
+    return lut, len(order)
+
+
+def numpy_expected(items, L, spec, vcf_text, sample_names, ref_bases):
+    """documented semantics, one item at a time, plain numpy.  Every input is independent of the product: the
+    variant table and the donor's genotype rows come from the ORACLE run on the source VCF text, the reference bases
+    from the array the test wrote, the channel map from independent_lut; only the random (region, donor) picks are
+    the dataset's (`items`)."""
+    from oracle import oracle
+    lut, C = independent_lut(spec)
     out1 = np.zeros((len(items), L, C), np.float32)
     out2 = np.zeros_like(out1)
+    enc = {}
     for b, it in enumerate(items):
         seq = np.full(L, ord("N"), np.uint8)
-        ref = ds.reference_genome.host_bases(it["chrom"]) if it["chrom"] in ds.reference_genome.contigs else None
+        ref = ref_bases.get(it["chrom"])
         if ref is not None:
             a, e = it["start"], min(it["start"] + L, len(ref))
             if e > a:
                 seq[: e - a] = ref[a:e]
         h = [seq.copy(), seq.copy()]
-        if it["group"] in ds.store.meta["groups"]:
-            start, vref, valt, _ = ds.store.variants(it["group"])
-            row = ds.store.sample_row(it["group"], it["donor"])
-            for j in range(len(start)):
-                off = int(start[j]) - it["start"]
-                if 0 <= off < L:
-                    for k in (0, 1):
-                        h[k][off] = valt[j] if row[j, k] == 1 else vref[j]
+        if it["chrom"] not in enc:
+            enc[it["chrom"]] = oracle.vcf_encode(vcf_text, len(sample_names), region=it["chrom"])
+        o = enc[it["chrom"]]
+        row = o["G"][sample_names.index(it["donor"])] if o["n_kept"] else np.zeros((0, 2), np.int8)
+        for j in range(o["n_kept"]):
+            off = int(o["start"][j]) - it["start"]
+            if 0 <= off < L:
+                for k in (0, 1):
+                    h[k][off] = o["alt"][j] if row[j, k] == 1 else o["ref"][j]
         for k, dst in ((0, out1), (1, out2)):
-            ch = ds.lut[h[k]]
+            ch = lut[h[k]]
             ok = ch < C
             dst[b, np.nonzero(ok)[0], ch[ok]] = 1.0
     return out1, out2
@@ -60,7 +78,7 @@ def numpy_expected(ds, items):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seq_length,batch,spec", [(1000, 4, None), (4096, 3, "ACGT"), (1001, 2, None)])
-def test_dataset_matches_numpy_restatement(ctx, tmp_path, golden_dir, seq_length, batch, spec):
+def test_dataset_matches_numpy_restatement(ctx, tmp_path, golden_dir, fixture_text, fixture_golden, seq_length, batch, spec):
     import shutil
     from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
     from haplohyped_varawareml_amd.dataset import RandomHaplotypeDataset
@@ -82,7 +100,7 @@ def test_dataset_matches_numpy_restatement(ctx, tmp_path, golden_dir, seq_length
     for _ in range(3):
         h1, h2 = ds[0]
         assert h1.shape == h2.shape == (batch, seq_length, C) and h1.dtype == h2.dtype == __import__("torch").float32
-        e1, e2 = numpy_expected(ds, ds.last_items)
+        e1, e2 = numpy_expected(ds.last_items, seq_length, spec, fixture_text, fixture_golden["samples"], {"chr22": seq})
         assert np.array_equal(h1.cpu().numpy(), e1) and np.array_equal(h2.cpu().numpy(), e2)
         assert float(h1.sum()) <= batch * seq_length
         n_var_total += sum(it["var_hi"] - it["var_lo"] for it in ds.last_items)
@@ -91,7 +109,7 @@ def test_dataset_matches_numpy_restatement(ctx, tmp_path, golden_dir, seq_length
 
 
 @pytest.mark.gpu
-def test_dataset_config5_shape(ctx, tmp_path, golden_dir):
+def test_dataset_config5_shape(ctx, tmp_path, golden_dir, fixture_text, fixture_golden):
     """BASELINE config 5: seq_length=131072, batch=32 -> two [32, 131072, 5] float32 tensors on the GPU"""
     import shutil
     import torch
@@ -103,7 +121,8 @@ def test_dataset_config5_shape(ctx, tmp_path, golden_dir):
     samples = os.path.join(golden_dir, "ipscs_samples_test.txt")
     store = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "out"), samples, 2, 1).run()
     rng = np.random.default_rng(2)
-    np.savez(tmp_path / "ref.npz", chr22=np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20_200_000)])
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20_200_000)]
+    np.savez(tmp_path / "ref.npz", chr22=seq)
     ds = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), store, str(tmp_path / "ref.npz"), samples,
                                 seed=42, batch_size=32, seq_length=131072, ctx=ctx)
     h1, h2 = ds[0]
@@ -111,14 +130,14 @@ def test_dataset_config5_shape(ctx, tmp_path, golden_dir):
     # every position has exactly one hot channel (reference bases are ACGT here)
     assert torch.equal(h1.sum(-1), torch.ones(32, 131072, device=h1.device))
     assert torch.equal(h2.sum(-1), torch.ones(32, 131072, device=h1.device))
-    e1, e2 = numpy_expected(ds, ds.last_items[:2])
+    e1, e2 = numpy_expected(ds.last_items[:2], 131072, None, fixture_text, fixture_golden["samples"], {"chr22": seq})
     assert np.array_equal(h1[:2].cpu().numpy(), e1) and np.array_equal(h2[:2].cpu().numpy(), e2)
     assert sum(it["var_hi"] - it["var_lo"] for it in ds.last_items) > 32     # windows do contain variants
     ds.close()
 
 
 @pytest.mark.gpu
-def test_dataset_reads_fasta_encoder_store(ctx, tmp_path, golden_dir):
+def test_dataset_reads_fasta_encoder_store(ctx, tmp_path, golden_dir, fixture_text, fixture_golden):
     """full chain of the reference's README: vcf_to_h5 + fasta_encoder -> RandomHaplotypeDataset"""
     import shutil
     from click.testing import CliRunner
@@ -143,10 +162,11 @@ def test_dataset_reads_fasta_encoder_store(ctx, tmp_path, golden_dir):
     ds = RandomHaplotypeDataset(os.path.join(golden_dir, "test_regions.bed"), store, ref_store, samples, seed=1,
                                 batch_size=4, seq_length=2000, ctx=ctx)
     h1, h2 = ds[0]
-    # the store keeps upper-cased bases with non-ACGT folded to N, exactly what the one-hot rule sees
-    e1, e2 = numpy_expected(ds, ds.last_items)
-    assert np.array_equal(h1.cpu().numpy(), e1) and np.array_equal(h2.cpu().numpy(), e2)
+    # expected values from the FASTA bytes the test wrote (the one-hot rule is case-insensitive), not from the store
     up = np.frombuffer(seq.upper(), dtype=np.uint8)
+    e1, e2 = numpy_expected(ds.last_items, 2000, None, fixture_text, fixture_golden["samples"],
+                            {"chr22": np.frombuffer(seq, dtype=np.uint8)})
+    assert np.array_equal(h1.cpu().numpy(), e1) and np.array_equal(h2.cpu().numpy(), e2)
     assert np.array_equal(ds.reference_genome.host_bases("chr22"), up)
     ds.close()
     # the same dataset over the exported HDF5 file (the reference's `hdf5_genotype_file` argument) instead of the store

@@ -70,9 +70,12 @@ def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
     mixed = synth.render_mixed("chr4", 900, 3, seed=4, names=names)
     write_bgzf(str(vcf_dir / "chr4.filtered.vcf.gz"), mixed)
     conv = VCFtoHDF5Converter("test_cohort", str(vcf_dir), str(tmp_path / "out"),
-                              os.path.join(golden_dir, "ipscs_samples_test.txt"), cores=2, cxx_threads=1)
-    store = conv.run()
-    assert store == str(tmp_path / "out" / "test_cohort.hhgt") and not os.path.exists(conv.tmp_dir)
+                              os.path.join(golden_dir, "ipscs_samples_test.txt"), cores=2, cxx_threads=1, n_gpus=1,
+                              keep_store=True)
+    out = conv.run()
+    assert out == str(tmp_path / "out" / "test_cohort.h5") == conv.h5_path      # the reference's artefact, vcf_to_h5.py:161
+    store = conv.store_path
+    assert os.path.isdir(store) and not os.path.exists(conv.tmp_dir)
     rd = VCFH5Reader(store, ctx=ctx)
     assert sorted(rd.store.groups()) == ["chr_22", "chr_4"]
     G22 = np.load(os.path.join(golden_dir, "fixture_G.npy"))
@@ -139,3 +142,86 @@ def test_converter_end_to_end(ctx, tmp_path, golden_dir, fixture_golden):
             assert np.array_equal(full["chr_22/genotype"], G22) and np.array_equal(full["chr_4/genotype"], o4["G"])
             assert np.array_equal(full[d0 + "|field|phase1"], G22[1, :, 0]) and np.array_equal(full[d0 + "|field|phase2"], G22[1, :, 1])
             assert full[d0 + "|field|chrom"][0] == b"chr22" and int(full[d0 + "|field|start"][0]) == 10012121
+
+
+def _same_tree(a, b, skip=()):
+    import filecmp
+    cmp = filecmp.dircmp(a, b, ignore=list(skip))
+    assert not cmp.left_only and not cmp.right_only, (cmp.left_only, cmp.right_only)
+    for f in cmp.common_files:
+        assert filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False), f
+    for d in cmp.common_dirs:
+        _same_tree(os.path.join(a, d), os.path.join(b, d), skip)
+
+
+def test_converter_two_workers_one_gpu(tmp_path, golden_dir, fixture_golden):
+    """VCFtoHDF5Converter.run with two GPU worker processes (both on this box's one GPU) against the in-process
+    run: identical store, identical OUT/{cohort}.h5; the default run removes the working store"""
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr22.filtered.vcf.gz"), vcf_dir / "chr22.filtered.vcf.gz")
+    names = fixture_golden["samples"]
+    write_bgzf(str(vcf_dir / "chr4.filtered.vcf.gz"), synth.render_mixed("chr4", 900, 3, seed=4, names=names))
+    tab = synth.variant_table(7, 20000, 3)
+    text, _ = synth.render_fixed_numpy("chr7", tab, 3, seed=7, names=names)
+    write_bgzf(str(vcf_dir / "chr7.filtered.vcf.gz"), text)
+    samples = os.path.join(golden_dir, "ipscs_samples_test.txt")
+    one = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "one"), samples, 2, 1, n_gpus=1, keep_store=True)
+    two = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "two"), samples, 2, 1, n_gpus=2, keep_store=True)
+    assert one.run() == one.h5_path and two.run() == two.h5_path
+    ranks = json.load(open(os.path.join(two.store_path, "ranks.json")))
+    assert ranks["world"] == 2 and {g["rank"] for g in ranks["groups"].values()} == {0, 1}
+    _same_tree(one.store_path, two.store_path, skip=["ranks.json"])
+    assert open(one.h5_path, "rb").read() == open(two.h5_path, "rb").read()
+    o7 = oracle.vcf_encode(text, 3, region="chr7")
+    from haplohyped_varawareml_amd.h5_reader import VCFH5Reader
+    rd = VCFH5Reader(two.h5_path)
+    rec = rd.fetch_genotypes(names[2], 7)
+    assert np.array_equal(rec["phase1"], o7["G"][2, :, 0]) and np.array_equal(rec["phase2"], o7["G"][2, :, 1])
+    dflt = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "dflt"), samples, 2, 1, n_gpus=1)
+    assert dflt.run() == dflt.h5_path and not os.path.exists(dflt.store_path)
+    assert open(dflt.h5_path, "rb").read() == open(one.h5_path, "rb").read()
+
+
+def test_header_only_chromosome(ctx, tmp_path, fixture_golden):
+    """a chromosome file with a header and no record: an empty group that neither the store nor the .h5 trips over"""
+    from haplohyped_varawareml_amd.vcf_to_h5 import VCFtoHDF5Converter
+    from haplohyped_varawareml_amd.h5_reader import VCFH5Reader
+    vcf_dir = tmp_path / "vcf"
+    vcf_dir.mkdir()
+    names = ["A", "B"]
+    write_bgzf(str(vcf_dir / "chr3.filtered.vcf.gz"), synth.header_text("chr3", names))
+    tab = synth.variant_table(5, 500, 2)
+    text, _ = synth.render_fixed_numpy("chr5", tab, 2, seed=5, names=names)
+    write_bgzf(str(vcf_dir / "chr5.filtered.vcf.gz"), text)
+    sl = tmp_path / "s.txt"
+    sl.write_text("A\nB")
+    conv = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "out"), str(sl), 2, 1, n_gpus=1, keep_store=True)
+    conv.run()
+    o5 = oracle.vcf_encode(text, 2, region="chr5")
+    for path in (conv.store_path, conv.h5_path):
+        rd = VCFH5Reader(path, ctx=ctx)
+        assert sorted(rd.store.groups()) == ["chr_3", "chr_5"]
+        assert len(rd.fetch_genotypes("A", 3)) == 0
+        rec = rd.fetch_genotypes("B", 5)
+        assert np.array_equal(rec["phase1"], o5["G"][1, :, 0]) and np.array_equal(rec["start"], o5["start"])
+
+
+def test_load_vcf_from_threads(golden_dir, fixture_golden):
+    """the reference calls load_vcf from ThreadPoolExecutor workers (vcf_to_h5.py:191-192)"""
+    from concurrent.futures import ThreadPoolExecutor
+    import parse_vcf
+    from haplohyped_varawareml_amd import parse_vcf as impl
+    impl._CACHE.clear()
+    path = os.path.join(golden_dir, "chr22.filtered.vcf.gz")
+    G = np.load(os.path.join(golden_dir, "fixture_G.npy"))
+    names = fixture_golden["samples"]
+    jobs = [(s, r) for r in ("chr22", "chr22:10000000-15000000", "") for s in range(3)] * 2
+    with ThreadPoolExecutor(6) as ex:
+        got = list(ex.map(lambda j: parse_vcf.load_vcf(path, names[j[0]], j[1]), jobs))
+    for (s, r), rows in zip(jobs, got):
+        want = parse_vcf.load_vcf(path, names[s], r)
+        assert rows == want
+        if r in ("chr22", ""):
+            assert [t[5] for t in rows] == G[s, :, 0].tolist() and [t[6] for t in rows] == G[s, :, 1].tolist()
