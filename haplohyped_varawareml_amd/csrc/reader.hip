@@ -1,6 +1,20 @@
-// reader.hip — host-side VCF text reader (see include/hhgt_reader.h): mmap + zlib inflate (BGZF blocks
-// in parallel, plain gzip streaming) into a ring of pinned, line-aligned blocks; hipMemcpyAsync to HBM.
-// Host C++ only (compiled by hipcc with the rest of libhhgt.so); no device code in this file.
+// reader.hip — host-side VCF text reader (see include/hhgt_reader.h): mmap + zlib inflate into a ring of pinned,
+// line-aligned blocks; hipMemcpyAsync to HBM.  Host C++ only (compiled by hipcc with the rest of libhhgt.so); no
+// device code in this file.
+//
+// BGZF (the format htslib reads under /root/reference/cpp/vcfpp.h:1381,1468): the scanner thread walks the member
+// headers — every member's inflated size sits in its trailer, so the place of every member's text in the ring is
+// known before anything is inflated — and hands the members to a pool of inflate workers as per-block task lists.
+// There is NO barrier per block: workers move from one block's list to the next while the scanner is already laying
+// out later blocks, and a block is published to the consumer when its last task finishes.  The one dependency
+// between blocks, the partial last line that moves to the front of the next block, is resolved by the scanner
+// itself: it inflates the block's LAST member right away (30 us of zlib), finds the last newline in it and thereby
+// knows where the next block's members start.  (Round 1 filled one block at a time with a wake-all / wait-all
+// around it: 48 threads delivered 20 GB/s of text where one delivers 2.2.)
+// Every member's text is hashed and compared with the CRC-32 in its trailer, as htslib's bgzf.c does; the hash is
+// the carry-less-multiply folding form (PCLMULQDQ), an order of magnitude faster than zlib 1.2.11's table crc32()
+// so the check no longer costs as much as the inflate it guards.  Plain gzip streams through one inflater,
+// uncompressed files are pread into the ring by the same worker pool.
 #include "common.h"
 #include "../../include/hhgt_reader.h"
 #include <zlib.h>
@@ -12,24 +26,40 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
 struct Task {
-    const uint8_t *src;
-    uint32_t src_len;
-    uint8_t *dst;
-    uint32_t dst_len;
+    const uint8_t *src = nullptr;
+    uint32_t src_len = 0;
+    uint8_t *dst = nullptr;
+    uint32_t dst_len = 0;
     int fd = -1;            // >= 0: an uncompressed piece, read with pread(fd, dst, dst_len, file_off)
     uint64_t file_off = 0;
     bool check_crc = false;  // BGZF member: compare crc32(dst) with the trailer behind src
 };
 
+// one ring block: its task list is written by the scanner before the block is opened to the workers
 struct Block {
     uint8_t *buf = nullptr;
-    size_t n = 0;
+    bool pinned = false;
+    size_t n = 0;                      // published bytes (whole lines)
+    std::vector<Task> tasks;
+    // generation << 32 | next task to draw.  Workers advance it by compare-and-swap against the generation they were
+    // given with the block, so a worker that still holds a recycled block can neither run a task of its next life
+    // nor swallow one of its tickets
+    std::atomic<uint64_t> ticket{0};
+    std::atomic<uint32_t> done{0};     // tasks finished
+    uint32_t gen = 0;
+    uint32_t n_tasks = 0;
+    bool scanned = false;              // layout complete (n, n_tasks final)
+    bool last = false;                 // last block of the input
 };
 
 }  // namespace
@@ -43,34 +73,58 @@ struct hhgt_reader {
     bool check_crc = true;   // HHGT_BGZF_NO_CRC=1 skips the per-member CRC32 (htslib always checks it)
     size_t block_bytes = 0;
     bool pinned = false;
-    std::vector<Block> ring;
-    std::deque<int> filled, free_;
-    int held = -1;
-    bool eof = false, stop = false;
+    int n_blocks = 0;
+    std::unique_ptr<Block[]> ring;
+    // block life cycle: free_ -> (scanner) open_ (workers draw tasks) -> order (publication order) -> held by the
+    // consumer -> free_
+    std::deque<int> free_, open_, order;
+    std::vector<char> held;          // per block: 1 while the consumer holds it
+    int auto_held = -1;              // block handed out by hhgt_reader_next (released by the following call)
+    bool eof = false, stop = false;  // eof: the scanner has laid out the last block
     int error = 0;
     std::string errmsg;
-    std::mutex mu;
-    std::condition_variable cv;
+    std::mutex mu;                   // guards the deques, eof/stop/error
+    std::condition_variable cv_free, cv_open, cv_pub;
     std::thread producer;
-    // BGZF worker pool
     std::vector<std::thread> workers;
-    std::vector<Task> tasks;
-    // ticket = generation << 32 | next task index: a worker that draws a ticket of a finished
-    // generation can never touch the task list of the next one
-    std::atomic<uint64_t> ticket{0};
-    std::atomic<uint64_t> open_gen{0};
-    std::atomic<size_t> n_tasks{0};
-    std::atomic<size_t> done_tasks{0};
-    std::atomic<int> task_err{0};
-    uint64_t batch_id = 0;
-    bool pool_stop = false;
-    std::mutex pmu;
-    std::condition_variable pcv, dcv;
     // plain gzip state
     z_stream zs;
     bool zs_init = false;
     std::atomic<uint64_t> text_bytes{0};
 };
+
+// Pinned ring blocks are expensive to make (hipHostMalloc pins page by page) and a converter opens one reader per
+// chromosome file: closed readers park their blocks here and the next open takes them back.
+static std::mutex g_pool_mu;
+static std::vector<std::pair<size_t, void *>> g_pool;
+#define POOL_MAX_BLOCKS 32
+
+static void *pool_take(size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].first == bytes) {
+            void *p = g_pool[i].second;
+            g_pool.erase(g_pool.begin() + (long)i);
+            return p;
+        }
+    return nullptr;
+}
+
+static bool pool_give(size_t bytes, void *p)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() >= POOL_MAX_BLOCKS) return false;
+    g_pool.emplace_back(bytes, p);
+    return true;
+}
+
+extern "C" void hhgt_reader_trim_pool(void)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &e : g_pool) hipHostFree(e.second);
+    g_pool.clear();
+}
 
 static bool looks_bgzf(const uint8_t *p, size_t n)
 {
@@ -78,8 +132,8 @@ static bool looks_bgzf(const uint8_t *p, size_t n)
            p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0;
 }
 
-// CRC-32 (RFC 1952) sixteen bytes per step: zlib 1.2.11's crc32() in this image runs near 1 GB/s per core, half of
-// what its inflate delivers on VCF text, and would make the check cost as much as the inflate it guards.
+// ---- CRC-32 (RFC 1952) --------------------------------------------------------------------------------------------
+// table form, sixteen bytes per step (portable path and tails)
 static uint32_t g_crc_tab[16][256];
 static std::once_flag g_crc_once;
 
@@ -94,10 +148,10 @@ static void crc_init()
         for (uint32_t i = 0; i < 256; ++i) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xFFu];
 }
 
-static uint32_t crc32_fast(const uint8_t *p, size_t n)
+// raw update: c is the running register (already inverted), returns the register
+static uint32_t crc32_table_update(uint32_t c, const uint8_t *p, size_t n)
 {
     std::call_once(g_crc_once, crc_init);
-    uint32_t c = 0xFFFFFFFFu;
     const uint32_t(*T)[256] = g_crc_tab;
     while (n >= 16) {
         uint32_t a, b, d, e;
@@ -114,10 +168,111 @@ static uint32_t crc32_fast(const uint8_t *p, size_t n)
         n -= 16;
     }
     while (n--) c = T[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
-    return ~c;
+    return c;
 }
 
-static int inflate_raw(z_stream *zs, const Task &t)
+#if defined(__x86_64__)
+// Carry-less-multiply folding (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", the
+// scheme zlib-ng / Chromium's zlib use): four 128-bit lanes are folded over the input 64 bytes per step, then
+// into one lane, then reduced to 32 bits (Barrett).  Constants are x^k mod P for the bit-reflected polynomial
+// 0xEDB88320.  n >= 64 and n % 16 == 0; the caller feeds the tail through the table form.
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_clmul_update(uint32_t crc, const uint8_t *buf, size_t len)
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x00000001c6e41596, 0x0000000154442bd4);
+    const __m128i k3k4 = _mm_set_epi64x(0x00000000ccaa009e, 0x00000001751997d0);
+    const __m128i k5k0 = _mm_set_epi64x(0x0000000000000000, 0x0000000163cd6124);
+    const __m128i poly = _mm_set_epi64x(0x00000001f7011641, 0x00000001db710641);
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
+    x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
+    x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = k1k2;
+    buf += 64;
+    len -= 64;
+    while (len >= 64) {   // fold four lanes in parallel
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+        x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+        x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+        x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+        x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
+        y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
+        y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64;
+        len -= 64;
+    }
+    x0 = k3k4;   // fold the four lanes into one
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {   // single-lane folds over the remaining 16-byte pieces
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16;
+        len -= 16;
+    }
+    // 128 -> 64 bits
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = k5k0;
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    // Barrett reduction 64 -> 32 bits
+    x0 = poly;
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+
+static bool have_clmul()
+{
+    static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    return ok;
+}
+#endif
+
+extern "C" uint32_t hhgt_crc32(const void *data, uint64_t n)
+{
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    uint32_t c = 0xFFFFFFFFu;
+#if defined(__x86_64__)
+    if (n >= 64 && have_clmul()) {
+        const size_t body = (size_t)n & ~(size_t)15;
+        c = crc32_clmul_update(c, p, body);
+        p += body;
+        n -= body;
+    }
+#endif
+    return ~crc32_table_update(c, p, (size_t)n);
+}
+
+// ---- tasks --------------------------------------------------------------------------------------------------------
+static int run_task(z_stream *zs, const Task &t)
 {
     if (t.fd >= 0) {
         // plain-text piece of an uncompressed file: pread straight into the pinned block.  (A memcpy out of the
@@ -142,73 +297,211 @@ static int inflate_raw(z_stream *zs, const Task &t)
         // not hash to it ("CRC32 checksum mismatch")
         const uint8_t *tr = t.src + t.src_len;
         const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
-        if (crc32_fast(t.dst, t.dst_len) != want) return -2;
+        if (hhgt_crc32(t.dst, t.dst_len) != want) return -2;
     }
     return 0;
 }
 
-static void run_tasks(hhgt_reader *r, z_stream *zs)
+static void set_error(hhgt_reader *r, const char *msg)
 {
-    for (;;) {
-        const uint64_t t = r->ticket.fetch_add(1);
-        const uint64_t gen = t >> 32, i = t & 0xFFFFFFFFull;
-        if (gen != r->open_gen.load() || i >= r->n_tasks.load()) break;
-        const int rc = inflate_raw(zs, r->tasks[i]);
-        if (rc != 0) r->task_err.store(rc == -2 ? 2 : 1);
-        r->done_tasks.fetch_add(1);
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (!r->error) {
+        r->error = HHGT_ERR_IO;
+        r->errmsg = msg;
     }
+    r->eof = true;
+    r->cv_pub.notify_all();
+    r->cv_open.notify_all();
+    r->cv_free.notify_all();
 }
+
+#define TASK_BATCH 4u
 
 static void worker_main(hhgt_reader *r)
 {
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     inflateInit2(&zs, -15);
-    uint64_t seen = 0;
     for (;;) {
+        int bi;
+        uint32_t gen, n_tasks;
         {
-            std::unique_lock<std::mutex> lk(r->pmu);
-            r->pcv.wait(lk, [&] { return r->pool_stop || r->batch_id != seen; });
-            if (r->pool_stop) break;
-            seen = r->batch_id;
+            std::unique_lock<std::mutex> lk(r->mu);
+            r->cv_open.wait(lk, [&] { return r->stop || !r->open_.empty(); });
+            if (r->stop) break;
+            bi = r->open_.front();
+            gen = r->ring[bi].gen;
+            n_tasks = r->ring[bi].n_tasks;
         }
-        run_tasks(r, &zs);
+        Block &b = r->ring[bi];
+        for (;;) {
+            uint64_t cur = b.ticket.load();
+            bool got = false;
+            while ((uint32_t)(cur >> 32) == gen && (uint32_t)cur < n_tasks) {
+                if (b.ticket.compare_exchange_weak(cur, cur + TASK_BATCH)) {
+                    got = true;
+                    break;
+                }
+            }
+            if (!got) break;
+            const uint32_t t0 = (uint32_t)cur;
+            const uint32_t t1 = t0 + TASK_BATCH < n_tasks ? t0 + TASK_BATCH : n_tasks;
+            for (uint32_t t = t0; t < t1; ++t) {
+                const int rc = run_task(&zs, b.tasks[t]);
+                if (rc != 0) set_error(r, rc == -2 ? "BGZF member: CRC32 checksum mismatch" : "inflate failed");
+            }
+            if (b.done.fetch_add(t1 - t0) + (t1 - t0) == n_tasks) {
+                std::lock_guard<std::mutex> lk(r->mu);   // the block's last task: it may be published now
+                r->cv_pub.notify_all();
+            }
+        }
         {
-            std::lock_guard<std::mutex> lk(r->pmu);
+            std::lock_guard<std::mutex> lk(r->mu);       // exhausted: take it off the open list (once per life)
+            if (!r->open_.empty() && r->open_.front() == bi && r->ring[bi].gen == gen) r->open_.pop_front();
         }
-        r->dcv.notify_all();
     }
     inflateEnd(&zs);
 }
 
-// fills dst[0, cap) with decompressed bytes; returns bytes produced (0 = end of input), <0 on error
-static long long run_batch(hhgt_reader *r);
-
-// uncompressed input: the copy into the pinned ring is split over the worker pool (one thread tops out
-// near 10 GB/s, well under what the PCIe link takes)
-static long long fill_plain(hhgt_reader *r, uint8_t *dst, size_t cap)
+// scanner side: a free block (waits), or -1 when the reader is closing
+static int take_free(hhgt_reader *r)
 {
-    size_t avail = r->map_len - r->in_pos;
-    size_t n = avail < cap ? avail : cap;
-    const size_t piece = 4u << 20;
-    if (n <= piece || r->workers.empty()) {
-        memcpy(dst, r->map + r->in_pos, n);
-    } else {
-        r->n_tasks.store(0);
-        r->tasks.clear();
-        for (size_t o = 0; o < n; o += piece) {
-            size_t l = n - o < piece ? n - o : piece;
-            Task t{r->map + r->in_pos + o, (uint32_t)l, dst + o, (uint32_t)l};
-            t.fd = r->fd;
-            t.file_off = r->in_pos + o;
-            r->tasks.push_back(t);
-        }
-        if (run_batch(r) < 0) return -1;
-    }
-    r->in_pos += n;
-    return (long long)n;
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv_free.wait(lk, [&] { return r->stop || !r->free_.empty(); });
+    if (r->stop) return -1;
+    int bi = r->free_.front();
+    r->free_.pop_front();
+    Block &b = r->ring[bi];
+    b.tasks.clear();
+    b.n_tasks = 0;
+    b.n = 0;
+    b.scanned = false;
+    b.last = false;
+    return bi;
 }
 
+// the block's layout is final: open it to the workers and put it in publication order
+static void open_block(hhgt_reader *r, int bi, size_t pub, bool last)
+{
+    Block &b = r->ring[bi];
+    b.n = pub;
+    b.n_tasks = (uint32_t)b.tasks.size();
+    b.last = last;
+    r->text_bytes.fetch_add(pub);
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        b.gen += 1;
+        b.done.store(0);
+        b.ticket.store((uint64_t)b.gen << 32);
+        b.scanned = true;
+        r->order.push_back(bi);
+        if (b.n_tasks) r->open_.push_back(bi);
+        if (last) r->eof = true;
+    }
+    r->cv_open.notify_all();
+    r->cv_pub.notify_all();
+}
+
+// ---- BGZF: barrier-free scanner --------------------------------------------------------------------------------
+static void scan_bgzf(hhgt_reader *r)
+{
+    std::vector<uint8_t> carry;   // partial last line of the previous block
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    inflateInit2(&zs, -15);
+    bool input_done = r->in_pos >= r->map_len;
+    while (!input_done) {
+        const int bi = take_free(r);
+        if (bi < 0) break;
+        Block &b = r->ring[bi];
+        size_t n = carry.size();
+        if (n) memcpy(b.buf, carry.data(), n);
+        carry.clear();
+        const size_t first_member_at = n;
+        // lay out members while they fit
+        while (r->in_pos < r->map_len) {
+            const uint8_t *p = r->map + r->in_pos;
+            const size_t left = r->map_len - r->in_pos;
+            if (!looks_bgzf(p, left)) {
+                set_error(r, "corrupt BGZF block header");
+                inflateEnd(&zs);
+                return;
+            }
+            const uint32_t bsize = (uint32_t)p[16] | ((uint32_t)p[17] << 8);
+            const size_t total = (size_t)bsize + 1;
+            if (total > left || total < 26) {
+                set_error(r, "truncated compressed input");
+                inflateEnd(&zs);
+                return;
+            }
+            const uint32_t isize = (uint32_t)p[total - 4] | ((uint32_t)p[total - 3] << 8) | ((uint32_t)p[total - 2] << 16) |
+                                   ((uint32_t)p[total - 1] << 24);
+            if (isize > 65536) {
+                set_error(r, "inflate failed");
+                inflateEnd(&zs);
+                return;
+            }
+            if (n + isize > r->block_bytes) break;
+            if (isize) {
+                Task t;
+                t.src = p + 18;
+                t.src_len = (uint32_t)(total - 18 - 8);
+                t.dst = b.buf + n;
+                t.dst_len = isize;
+                t.check_crc = r->check_crc;
+                b.tasks.push_back(t);
+            }
+            n += isize;
+            r->in_pos += total;
+        }
+        input_done = r->in_pos >= r->map_len;
+        if (b.tasks.empty() && !input_done) {
+            set_error(r, "a line is longer than the reader's block size");
+            break;
+        }
+        size_t pub = n;
+        if (!input_done) {
+            // Where does the last whole line end?  Inflate members from the back (normally just the last one) until
+            // one holds a newline; they are done here, so they leave the task list.
+            size_t cut = (size_t)-1;
+            while (!b.tasks.empty()) {
+                const Task t = b.tasks.back();
+                b.tasks.pop_back();
+                const int rc = run_task(&zs, t);
+                if (rc != 0) {
+                    set_error(r, rc == -2 ? "BGZF member: CRC32 checksum mismatch" : "inflate failed");
+                    inflateEnd(&zs);
+                    return;
+                }
+                const void *nl = memrchr(t.dst, '\n', t.dst_len);
+                if (nl) {
+                    cut = (size_t)((const uint8_t *)nl - b.buf) + 1;
+                    break;
+                }
+            }
+            if (cut == (size_t)-1) {
+                // no newline in any member of this block: only the carried bytes may hold one
+                const void *nl = first_member_at ? memrchr(b.buf, '\n', first_member_at) : nullptr;
+                if (!nl) {
+                    set_error(r, "a line is longer than the reader's block size");
+                    break;
+                }
+                cut = (size_t)((const uint8_t *)nl - b.buf) + 1;
+            }
+            pub = cut;
+            carry.assign(b.buf + cut, b.buf + n);
+        }
+        open_block(r, bi, pub, input_done);
+    }
+    inflateEnd(&zs);
+    if (input_done) {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->eof = true;
+        r->cv_pub.notify_all();
+    }
+}
+
+// ---- plain gzip (one stream) and uncompressed input ------------------------------------------------------------
 static long long fill_gzip(hhgt_reader *r, uint8_t *dst, size_t cap)
 {
     size_t produced = 0;
@@ -242,130 +535,74 @@ static long long fill_gzip(hhgt_reader *r, uint8_t *dst, size_t cap)
     return (long long)produced;
 }
 
-static long long fill_bgzf(hhgt_reader *r, uint8_t *dst, size_t cap)
-{
-    r->n_tasks.store(0);  // closes the previous generation before the list is rewritten
-    r->tasks.clear();
-    size_t produced = 0;
-    while (r->in_pos < r->map_len) {
-        const uint8_t *p = r->map + r->in_pos;
-        size_t left = r->map_len - r->in_pos;
-        if (!looks_bgzf(p, left)) return -3;
-        uint32_t bsize = (uint32_t)p[16] | ((uint32_t)p[17] << 8);
-        size_t total = (size_t)bsize + 1;
-        if (total > left || total < 26) return -2;
-        uint32_t isize = (uint32_t)p[total - 4] | ((uint32_t)p[total - 3] << 8) | ((uint32_t)p[total - 2] << 16) |
-                         ((uint32_t)p[total - 1] << 24);
-        if (isize > 65536) return -1;
-        if (produced + isize > cap) break;
-        if (isize) {
-            Task t{p + 18, (uint32_t)(total - 18 - 8), dst + produced, isize};
-            t.check_crc = r->check_crc;
-            r->tasks.push_back(t);
-        }
-        produced += isize;
-        r->in_pos += total;
-    }
-    const long long rb = run_batch(r);
-    if (rb < 0) return rb;
-    return (long long)produced;
-}
-
-// runs r->tasks on the worker pool (the calling producer thread helps); <0 on failure
-static long long run_batch(hhgt_reader *r)
-{
-    if (r->tasks.empty()) return 0;
-    r->done_tasks.store(0);
-    {
-        std::lock_guard<std::mutex> lk(r->pmu);
-        r->batch_id++;
-        r->open_gen.store(r->batch_id);
-        r->n_tasks.store(r->tasks.size());
-        r->ticket.store(r->batch_id << 32);
-    }
-    r->pcv.notify_all();
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    inflateInit2(&zs, -15);
-    run_tasks(r, &zs);
-    inflateEnd(&zs);
-    {
-        std::unique_lock<std::mutex> lk(r->pmu);
-        r->dcv.wait(lk, [&] { return r->done_tasks.load() >= r->tasks.size(); });
-    }
-    return r->task_err.load() == 2 ? -4 : (r->task_err.load() ? -1 : 0);
-}
-
-static void producer_main(hhgt_reader *r)
+static void scan_stream(hhgt_reader *r)
 {
     std::vector<uint8_t> carry;
-    bool input_done = false;
+    bool input_done = r->map_len == 0;
     while (!input_done) {
-        int bi;
-        {
-            std::unique_lock<std::mutex> lk(r->mu);
-            r->cv.wait(lk, [&] { return r->stop || !r->free_.empty(); });
-            if (r->stop) return;
-            bi = r->free_.front();
-            r->free_.pop_front();
-        }
+        const int bi = take_free(r);
+        if (bi < 0) return;
         Block &b = r->ring[bi];
         size_t n = carry.size();
         if (n) memcpy(b.buf, carry.data(), n);
         carry.clear();
-        // fill until the block is (nearly) full or the input ends
-        for (;;) {
-            size_t cap = r->block_bytes - n;
-            if (cap < 65536 + 1) break;
-            long long got = r->is_bgzf ? fill_bgzf(r, b.buf + n, cap)
-                            : r->is_gzip ? fill_gzip(r, b.buf + n, cap)
-                                         : fill_plain(r, b.buf + n, cap);
+        size_t pub;
+        if (r->is_gzip) {
+            const long long got = fill_gzip(r, b.buf + n, r->block_bytes - n);
             if (got < 0) {
-                std::lock_guard<std::mutex> lk(r->mu);
-                r->error = HHGT_ERR_IO;
-                r->errmsg = got == -2 ? "truncated compressed input" : got == -3 ? "corrupt BGZF block header" : got == -4 ? "BGZF member: CRC32 checksum mismatch" : "inflate failed";
-                r->eof = true;
-                r->cv.notify_all();
+                set_error(r, got == -2 ? "truncated compressed input" : "inflate failed");
                 return;
             }
-            if (got == 0) {
-                if (r->in_pos >= r->map_len) input_done = true;
-                break;
-            }
             n += (size_t)got;
-            if (!r->is_bgzf) break;  // gzip/plain fill the whole capacity in one call
-        }
-        if (!r->is_bgzf && r->in_pos >= r->map_len && !r->zs_init) input_done = true;
-        size_t pub = n;
-        if (!input_done) {
-            // cut at the last newline; the partial line moves to the next block
-            const void *nl = n ? memrchr(b.buf, '\n', n) : nullptr;
-            if (!nl) {
-                if (n + 65536 + 1 > r->block_bytes) {
-                    std::lock_guard<std::mutex> lk(r->mu);
-                    r->error = HHGT_ERR_IO;
-                    r->errmsg = "a line is longer than the reader's block size";
-                    r->eof = true;
-                    r->cv.notify_all();
+            input_done = r->in_pos >= r->map_len && !r->zs_init;
+            if (got == 0 && !input_done) input_done = r->in_pos >= r->map_len;
+            pub = n;
+            if (!input_done) {
+                const void *nl = n ? memrchr(b.buf, '\n', n) : nullptr;
+                if (!nl) {
+                    set_error(r, "a line is longer than the reader's block size");
                     return;
                 }
-                pub = 0;
-                carry.assign(b.buf, b.buf + n);
-            } else {
                 pub = (size_t)((const uint8_t *)nl - b.buf) + 1;
                 carry.assign(b.buf + pub, b.buf + n);
             }
+        } else {
+            // uncompressed: the cut is found in the mapping itself, the bytes are pread by the workers
+            const size_t avail = r->map_len - r->in_pos;
+            size_t take = avail < r->block_bytes - n ? avail : r->block_bytes - n;
+            input_done = take == avail;
+            if (!input_done) {
+                const void *nl = memrchr(r->map + r->in_pos, '\n', take);
+                if (!nl) {
+                    set_error(r, "a line is longer than the reader's block size");
+                    return;
+                }
+                take = (size_t)((const uint8_t *)nl - (r->map + r->in_pos)) + 1;
+            }
+            const size_t piece = 4u << 20;
+            for (size_t o = 0; o < take; o += piece) {
+                Task t;
+                t.dst = b.buf + n + o;
+                t.dst_len = (uint32_t)(take - o < piece ? take - o : piece);
+                t.fd = r->fd;
+                t.file_off = r->in_pos + o;
+                b.tasks.push_back(t);
+            }
+            r->in_pos += take;
+            n += take;
+            pub = n;
         }
-        b.n = pub;
-        r->text_bytes.fetch_add(pub);
-        {
-            std::lock_guard<std::mutex> lk(r->mu);
-            if (pub) r->filled.push_back(bi);
-            else r->free_.push_back(bi);
-            if (input_done) r->eof = true;
-        }
-        r->cv.notify_all();
+        open_block(r, bi, pub, input_done);
     }
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->eof = true;
+    r->cv_pub.notify_all();
+}
+
+static void producer_main(hhgt_reader *r)
+{
+    if (r->is_bgzf) scan_bgzf(r);
+    else scan_stream(r);
 }
 
 extern "C" int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_threads, int n_blocks, hhgt_reader **out)
@@ -373,7 +610,7 @@ extern "C" int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_th
     if (!path || !out) return HHGT_ERR_ARG;
     *out = nullptr;
     if (block_bytes < (1u << 20)) block_bytes = 1u << 20;
-    if (n_blocks <= 0) n_blocks = 3;
+    if (n_blocks <= 0) n_blocks = 4;
     if (n_blocks < 2) n_blocks = 2;
     int fd = open(path, O_RDONLY);
     if (fd < 0) {
@@ -407,34 +644,38 @@ extern "C" int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_th
         r->check_crc = !(e && *e && *e != '0');
     }
     r->block_bytes = (size_t)block_bytes;
-    r->ring.resize((size_t)n_blocks);
+    r->n_blocks = n_blocks;
+    r->ring.reset(new Block[(size_t)n_blocks]);
+    r->held.assign((size_t)n_blocks, 0);
     // pinned when a HIP device exists (the copy engine can then DMA straight out of the ring);
     // plain pages otherwise (CPU-only hosts still frame and inflate, e.g. in the CPU test suite)
     int ndev = 0;
     r->pinned = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
-    for (auto &b : r->ring) {
-        void *p = nullptr;
-        if (r->pinned && hipHostMalloc(&p, r->block_bytes, hipHostMallocDefault) != hipSuccess) {
-            r->pinned = false;
+    for (int i = 0; i < n_blocks; ++i) {
+        void *p = r->pinned ? pool_take(r->block_bytes) : nullptr;
+        if (!p && r->pinned && hipHostMalloc(&p, r->block_bytes, hipHostMallocDefault) != hipSuccess) {
+            r->pinned = false;   // (blocks already taken stay pinned: pinned and pageable memory are freed alike below)
             p = nullptr;
         }
+        r->ring[i].pinned = p != nullptr;
         if (!p) p = malloc(r->block_bytes);
         if (!p) {
             hhgt_set_error("reader: out of memory for %zu-byte blocks", r->block_bytes);
             hhgt_reader_close(r);
             return HHGT_ERR_IO;
         }
-        b.buf = static_cast<uint8_t *>(p);
+        r->ring[i].buf = static_cast<uint8_t *>(p);
+        r->free_.push_back(i);
     }
-    for (int i = 0; i < n_blocks; ++i) r->free_.push_back(i);
     if (r->is_bgzf || !r->is_gzip) {
         unsigned hw = std::thread::hardware_concurrency();
-        // measured on the 256-thread host of an MI355X box: 32-64 inflate threads saturate (~20 GB/s of text);
-        // more threads lose to wake-up and memory contention
-        int nt = n_threads > 0 ? n_threads : (hw ? (int)(hw < 48 ? hw : 48) : 4);
+        // BGZF default: one worker per physical-core-ish (half the hardware threads), at most 96; HHGT_READER_THREADS
+        // or the n_threads argument override.  Uncompressed input: 16 pread threads saturate the page cache copy.
+        const char *e = getenv("HHGT_READER_THREADS");
+        int nt = n_threads > 0 ? n_threads : (e && atoi(e) > 0 ? atoi(e) : (hw ? (int)(hw / 2 < 96 ? (hw / 2 ? hw / 2 : 1) : 96) : 4));
         if (nt > 192) nt = 192;
-        if (!r->is_bgzf && nt > 16) nt = 16;  // plain pread copies: 16 threads 28 GB/s, 32 threads 25 GB/s (contention)
-        for (int i = 0; i < nt - 1; ++i) r->workers.emplace_back(worker_main, r);
+        if (!r->is_bgzf && nt > 16) nt = 16;
+        for (int i = 0; i < nt; ++i) r->workers.emplace_back(worker_main, r);
     }
     r->producer = std::thread(producer_main, r);
     *out = r;
@@ -448,19 +689,19 @@ extern "C" void hhgt_reader_close(hhgt_reader *r)
         std::lock_guard<std::mutex> lk(r->mu);
         r->stop = true;
     }
-    r->cv.notify_all();
+    r->cv_free.notify_all();
+    r->cv_open.notify_all();
+    r->cv_pub.notify_all();
     if (r->producer.joinable()) r->producer.join();
-    {
-        std::lock_guard<std::mutex> lk(r->pmu);
-        r->pool_stop = true;
-    }
-    r->pcv.notify_all();
     for (auto &t : r->workers) t.join();
     if (r->zs_init) inflateEnd(&r->zs);
-    for (auto &b : r->ring) {
-        if (!b.buf) continue;
-        if (r->pinned) hipHostFree(b.buf);
-        else free(b.buf);
+    for (int i = 0; i < r->n_blocks; ++i) {
+        uint8_t *b = r->ring[i].buf;
+        if (!b) continue;
+        if (r->ring[i].pinned) {
+            if (!pool_give(r->block_bytes, b)) hipHostFree(b);
+        } else
+            free(b);
     }
     if (r->map) munmap(const_cast<uint8_t *>(r->map), r->map_len);
     if (r->fd >= 0) close(r->fd);
@@ -469,30 +710,69 @@ extern "C" void hhgt_reader_close(hhgt_reader *r)
 
 extern "C" int hhgt_reader_is_bgzf(const hhgt_reader *r) { return r && r->is_bgzf ? 1 : 0; }
 
-extern "C" int hhgt_reader_next(hhgt_reader *r, const void **host_ptr, uint64_t *nbytes)
+extern "C" int hhgt_reader_acquire(hhgt_reader *r, const void **host_ptr, uint64_t *nbytes, int *token, int *is_last)
 {
-    if (!r || !host_ptr || !nbytes) return HHGT_ERR_ARG;
+    if (!r || !host_ptr || !nbytes || !token) return HHGT_ERR_ARG;
     *host_ptr = nullptr;
     *nbytes = 0;
+    *token = -1;
+    if (is_last) *is_last = 0;
     std::unique_lock<std::mutex> lk(r->mu);
-    if (r->held >= 0) {
-        r->free_.push_back(r->held);
-        r->held = -1;
-        r->cv.notify_all();
-    }
-    r->cv.wait(lk, [&] { return !r->filled.empty() || r->eof; });
-    if (r->filled.empty()) {
+    for (;;) {
         if (r->error) {
             hhgt_set_error("reader: %s", r->errmsg.c_str());
             return r->error;
         }
-        return HHGT_OK;  // end of file
+        if (!r->order.empty()) {
+            Block &b = r->ring[r->order.front()];
+            if (b.scanned && b.done.load() >= b.n_tasks) break;
+        } else if (r->eof) {
+            return HHGT_OK;  // end of file
+        }
+        if (r->stop) return HHGT_OK;
+        r->cv_pub.wait(lk);
     }
-    r->held = r->filled.front();
-    r->filled.pop_front();
-    *host_ptr = r->ring[r->held].buf;
-    *nbytes = r->ring[r->held].n;
+    const int bi = r->order.front();
+    r->order.pop_front();
+    Block &b = r->ring[bi];
+    if (b.n == 0) {   // an empty block (e.g. only empty members): recycle and look again
+        r->free_.push_back(bi);
+        r->cv_free.notify_all();
+        const bool last = b.last;
+        lk.unlock();
+        if (last) return HHGT_OK;
+        return hhgt_reader_acquire(r, host_ptr, nbytes, token, is_last);
+    }
+    r->held[(size_t)bi] = 1;
+    *host_ptr = b.buf;
+    *nbytes = b.n;
+    *token = bi;
+    if (is_last) *is_last = b.last ? 1 : 0;
     return HHGT_OK;
+}
+
+extern "C" int hhgt_reader_release(hhgt_reader *r, int token)
+{
+    if (!r || token < 0 || token >= r->n_blocks) return HHGT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (!r->held[(size_t)token]) return HHGT_ERR_ARG;
+    r->held[(size_t)token] = 0;
+    r->free_.push_back(token);
+    r->cv_free.notify_all();
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_reader_next(hhgt_reader *r, const void **host_ptr, uint64_t *nbytes)
+{
+    if (!r || !host_ptr || !nbytes) return HHGT_ERR_ARG;
+    if (r->auto_held >= 0) {
+        hhgt_reader_release(r, r->auto_held);
+        r->auto_held = -1;
+    }
+    int token = -1;
+    const int rc = hhgt_reader_acquire(r, host_ptr, nbytes, &token, nullptr);
+    if (rc == HHGT_OK) r->auto_held = token;
+    return rc;
 }
 
 extern "C" int hhgt_reader_copy_async(hhgt_reader *r, const void *host_ptr, uint64_t nbytes, void *d_dst, void *stream)
@@ -507,5 +787,92 @@ extern "C" int hhgt_reader_stats(const hhgt_reader *r, uint64_t *file_bytes, uin
     if (!r) return HHGT_ERR_ARG;
     if (file_bytes) *file_bytes = r->in_pos;
     if (text_bytes) *text_bytes = r->text_bytes.load();
+    return HHGT_OK;
+}
+
+// ---- bench / test tooling: parallel BGZF writer (declared in include/hhgt_synth.h) ---------------------------------
+#include "../../include/hhgt_synth.h"
+#include <stdio.h>
+
+static bool bgzf_member(z_stream *zs, int level, const uint8_t *src, uint32_t n, std::vector<uint8_t> &out)
+{
+    const size_t at = out.size();
+    out.resize(at + 18 + 65536 + 8);
+    uint8_t *h = out.data() + at;
+    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(h, head, 16);
+    (void)level;
+    if (deflateReset(zs) != Z_OK) return false;
+    zs->next_in = const_cast<Bytef *>(src);
+    zs->avail_in = n;
+    zs->next_out = h + 18;
+    zs->avail_out = 65536 - 18 - 8;
+    if (deflate(zs, Z_FINISH) != Z_STREAM_END) return false;
+    const uint32_t clen = (uint32_t)(65536 - 18 - 8 - zs->avail_out);
+    const uint32_t bsize = clen + 25;   // total member size - 1
+    h[16] = (uint8_t)(bsize & 0xFF);
+    h[17] = (uint8_t)(bsize >> 8);
+    uint8_t *t = h + 18 + clen;
+    const uint32_t crc = hhgt_crc32(src, n);
+    for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));
+    for (int k = 0; k < 4; ++k) t[4 + k] = (uint8_t)(n >> (8 * k));
+    out.resize(at + 18 + clen + 8);
+    return true;
+}
+
+extern "C" int hhgt_synth_write_bgzf(const char *path, const void *text, uint64_t nbytes, int level, int n_threads)
+{
+    if (!path || (!text && nbytes)) return HHGT_ERR_ARG;
+    const uint32_t piece = 0xFF00;
+    const uint64_t n_members = (nbytes + piece - 1) / piece;
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : (int)(hw ? hw : 4);
+    if ((uint64_t)nt > n_members) nt = (int)(n_members ? n_members : 1);
+    std::vector<std::vector<uint8_t>> parts((size_t)nt);
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    const uint8_t *src = static_cast<const uint8_t *>(text);
+    for (int i = 0; i < nt; ++i) {
+        th.emplace_back([&, i] {
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                bad.store(1);
+                return;
+            }
+            const uint64_t m0 = n_members * (uint64_t)i / (uint64_t)nt, m1 = n_members * (uint64_t)(i + 1) / (uint64_t)nt;
+            parts[(size_t)i].reserve((size_t)((m1 - m0) * 4096));
+            for (uint64_t m = m0; m < m1; ++m) {
+                const uint64_t o = m * piece;
+                const uint32_t n = (uint32_t)(nbytes - o < piece ? nbytes - o : piece);
+                if (!bgzf_member(&zs, level, src + o, n, parts[(size_t)i])) {
+                    bad.store(1);   // (incompressible input would need a smaller member; the generator's text never is)
+                    break;
+                }
+            }
+            deflateEnd(&zs);
+        });
+    }
+    for (auto &t : th) t.join();
+    if (bad.load()) {
+        hhgt_set_error("write_bgzf: deflate failed");
+        return HHGT_ERR_IO;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        hhgt_set_error("cannot create %s", path);
+        return HHGT_ERR_IO;
+    }
+    bool ok = true;
+    for (auto &p : parts) ok = ok && (p.empty() || fwrite(p.data(), 1, p.size(), f) == p.size());
+    // empty end-of-file member, as bgzip writes it (deflate of nothing = 03 00)
+    static const uint8_t eof_member[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0,
+                                           0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_member, 1, 28, f) == 28;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        hhgt_set_error("short write to %s", path);
+        return HHGT_ERR_IO;
+    }
     return HHGT_OK;
 }

@@ -197,10 +197,72 @@ class _DeviceBgzfBlocks:
         self.raw = None
 
 
+class RawColumns:
+    """what on_columns gets as its first argument from the native engine: the size of the uncompressed columns
+    (the engine hands out framed chunks only; the legacy loop passes the device tensor itself)"""
+
+    def __init__(self, nbytes):
+        self._n = int(nbytes)
+
+    def numel(self):
+        return self._n
+
+
+def _want_device_inflate(device_inflate):
+    if device_inflate is None:
+        return os.environ.get("HHGT_DEVICE_INFLATE", "0") not in ("", "0")
+    return bool(device_inflate)
+
+
+def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=None, n_threads=0, sites_only=False,
+                 fmt=dev.BLOSC2, device_inflate=None, on_header=None, on_variants=None, on_columns=None, on_end=None,
+                 files_ahead=1):
+    """Several inputs through ONE native ingest engine (csrc/ingest.hip): the inflate of the next file overlaps the
+    encode of the current one, and nothing waits on the host between blocks.
+    jobs: [(path_or_host_buffer, region)]; callbacks get the job index first:
+        on_header(i, sample_names)   on_variants(i, start, ref, alt)   on_columns(i, RawColumns, n_cols, (bytes, offsets))
+        on_end(i, FileStats)
+    -> [FileStats] in job order"""
+    from .ingest import Columns, Header, Ingest, InputEnd, Variants
+    stats = [FileStats() for _ in jobs]
+    with Ingest(ctx, sc=sc, vc=vc, fmt=fmt, sites_only=sites_only, device_inflate=_want_device_inflate(device_inflate),
+                n_threads=n_threads, block_bytes=block_bytes or 0, files_ahead=files_ahead) as ing:
+        for src, region in jobs:
+            if isinstance(src, (str, os.PathLike)):
+                ing.add_file(src, region)
+            else:
+                ing.add_memory(src, region)
+        ing.finish()
+        for ev in ing.events():
+            fs = stats[ev.input]
+            if isinstance(ev, Header):
+                names, _ = parse_header(np.frombuffer(ev.header, dtype=np.uint8))
+                fs.samples = names
+                if on_header:
+                    on_header(ev.input, names)
+            elif isinstance(ev, Variants):
+                fs.chrom_runs.extend(ev.runs)
+                if on_variants and len(ev.start):
+                    on_variants(ev.input, ev.start, ev.ref, ev.alt)
+            elif isinstance(ev, Columns):
+                if on_columns:
+                    on_columns(ev.input, RawColumns(ev.raw_bytes), ev.n_cols, (ev.framed, ev.chunk_off))
+            elif isinstance(ev, InputEnd):
+                for k, v in ev.stats.items():
+                    if hasattr(fs, k):
+                        setattr(fs, k, v)
+                fs.is_bgzf = bool(ev.stats["is_bgzf"])
+                if on_end:
+                    on_end(ev.input, fs)
+    return stats
+
+
 def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=None, n_threads=0,
                 sites_only=False, on_columns=None, on_variants=None, on_header=None, compress=True, fmt=dev.BLOSC2,
                 device_inflate=None):
-    """Streams one VCF through the device path.
+    """Streams one VCF through the device path.  With compress=True and a chunk-tiled layout (the converter's case)
+    the native engine runs it (stream_files); otherwise the Python loop below (dense / uncompressed columns handed
+    out as device tensors: the parse_vcf facade and tests).
     on_header(samples)                         once
     on_variants(start, ref, alt)               numpy arrays for each text block's kept records
     on_columns(G_cols, n_cols, framed)         for every batch of completed chunk columns:
@@ -209,11 +271,16 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
     device_inflate: BGZF members are inflated on the device instead of by the host reader threads (None: the
         HHGT_DEVICE_INFLATE environment variable, default off — the north star keeps BGZF on the host)
     -> FileStats"""
+    if compress and sc and not sites_only:
+        return stream_files(ctx, [(path, region)], sc=sc, vc=vc, block_bytes=block_bytes, n_threads=n_threads, fmt=fmt,
+                            device_inflate=device_inflate,
+                            on_header=(lambda i, names: on_header(names)) if on_header else None,
+                            on_variants=(lambda i, a, b, c: on_variants(a, b, c)) if on_variants else None,
+                            on_columns=(lambda i, g, n, f: on_columns(g, n, f)) if on_columns else None)[0]
     t_start = time.perf_counter()
     fs = FileStats()
     d = ctx.device
-    if device_inflate is None:
-        device_inflate = os.environ.get("HHGT_DEVICE_INFLATE", "0") not in ("", "0")
+    device_inflate = _want_device_inflate(device_inflate)
     if device_inflate and _is_bgzf_file(path):
         # one wave per member: a launch wants >= 10 k members (64 KiB of text each) to fill the chip, so the text
         # block is 1 GiB unless the file is smaller (measured: 64 MiB blocks 1.4 M variants/s, 1 GiB 4.0 M)

@@ -108,6 +108,16 @@ def parse_header(block):
     return names, min(pos, len(buf))
 
 
+def write_bgzf_native(path, data, level=6, n_threads=0):
+    """the same file as write_bgzf, members deflated in parallel by libhhgt (`hhgt_synth_write_bgzf`; bench tooling).
+    data: bytes-like or a uint8 numpy array (not copied)"""
+    L = _lib.load()
+    L.hhgt_synth_write_bgzf.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+    a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    check(L.hhgt_synth_write_bgzf(str(path).encode(), C.c_void_p(a.ctypes.data), a.size, int(level), int(n_threads)))
+
+
 def write_bgzf(path, data, block_size=0xFF00, level=6):
     """Minimal BGZF writer (test/bench tooling: BASELINE.md §3 asks for BGZF-compressed synthetic
     shards; htslib/bgzip are not in the image)."""

@@ -72,13 +72,15 @@ def merge_stores(parts, final_path, group_order):
 
 
 def _default_stream():
-    from .pipeline import stream_file
-    return stream_file
+    from .pipeline import stream_files
+    return stream_files
 
 
 def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=None, make_ctx=None):
-    """the work of one rank: its chromosome files -> groups of the (partial) store at part_path.
+    """the work of one rank: its chromosome files -> groups of the (partial) store at part_path, all through ONE
+    ingest engine (pipeline.stream_files): while chromosome k is being encoded, the host threads already inflate k+1.
     stream_fn / make_ctx exist so that the CPU test suite can drive the rank / merge logic without a GPU."""
+    from ._lib import BLOSC1      # filter 32001 = hdf5-blosc: Blosc-1 chunk framing
     from .device import DEFAULT_SC, DEFAULT_VC
     from .store import StoreWriter
     stream_fn = stream_fn or _default_stream()
@@ -89,16 +91,35 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
     writer = StoreWriter(part_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=conv.cohort_name,
                          donor_ids=[d for d in conv.donor_ids if d], chunk_format="blosc1")
     stats = {}
+    jobs = [(os.path.join(conv.vcf_dir, f"chr{c}.filtered.vcf.gz"), f"chr{c}") for c in chromosomes]
+
+    def on_header(i, names):
+        missing = [d for d in conv.donor_ids if d and d not in names]
+        if missing:   # cpp/vcfpp.h:373-377
+            raise RuntimeError(f"Error parsing VCF file: the {len(missing)}-th sample are not in the VCF.\n"
+                               f"parameter samples:{missing[0]}")
+        if writer.meta["samples"] != list(names):
+            if writer.meta["groups"]:
+                raise RuntimeError(f"{jobs[i][0]}: sample columns differ from the previous chromosome files")
+            writer.meta["samples"] = list(names)
+        writer.begin_group(f"chr_{chromosomes[i]}")
+
+    def on_end(i, fs):
+        group = f"chr_{chromosomes[i]}"
+        writer.add_chrom_runs(fs.chrom_runs)
+        writer.end_group()
+        conv.stats[group] = fs
+        stats[group] = dict(n_kept=fs.n_kept, n_samples=fs.n_samples, n_lines=fs.n_lines, seconds=fs.seconds,
+                            raw_bytes=fs.raw_bytes, compressed_bytes=fs.compressed_bytes, rank=rank, device=device)
+        logger.info(f"[gpu {device}] chr{chromosomes[i]}: {fs.n_kept} SNPs x {fs.n_samples} samples in {fs.seconds:.2f}s "
+                    f"({fs.n_lines / max(fs.seconds, 1e-9):.0f} lines/s), ratio "
+                    f"{fs.raw_bytes / max(fs.compressed_bytes, 1):.2f}")
+
     try:
-        for chromosome in chromosomes:
-            vcf_file = os.path.join(conv.vcf_dir, f"chr{chromosome}.filtered.vcf.gz")
-            fs = conv.genotype_vcf_to_store(ctx, writer, vcf_file, chromosome, stream_fn=stream_fn)
-            stats[f"chr_{chromosome}"] = dict(n_kept=fs.n_kept, n_samples=fs.n_samples, n_lines=fs.n_lines,
-                                              seconds=fs.seconds, raw_bytes=fs.raw_bytes,
-                                              compressed_bytes=fs.compressed_bytes, rank=rank, device=device)
-            logger.info(f"[gpu {device}] chr{chromosome}: {fs.n_kept} SNPs x {fs.n_samples} samples in {fs.seconds:.2f}s "
-                        f"({fs.n_lines / max(fs.seconds, 1e-9):.0f} lines/s), ratio "
-                        f"{fs.raw_bytes / max(fs.compressed_bytes, 1):.2f}")
+        if jobs:
+            stream_fn(ctx, jobs, sc=writer.meta["sc"], vc=writer.meta["vc"], n_threads=conv.cores or 0, fmt=BLOSC1,
+                      on_header=on_header, on_variants=lambda i, a, b, c: writer.add_variants(a, b, c),
+                      on_columns=lambda i, g, n, framed: writer.add_chunks(framed[0], framed[1], g.numel()), on_end=on_end)
         writer.close()
     finally:
         if hasattr(ctx, "close"):
@@ -182,10 +203,11 @@ class VCFtoHDF5Converter:
         """the reference's output file (vcf_to_h5.py:161)"""
         return os.path.join(self.out_dir, f"{self.cohort_name}.h5")
 
-    def genotype_vcf_to_store(self, ctx, writer, data_path: str, chromosome: int, stream_fn=None):
-        """one chromosome file -> group chr_{N} (all samples at once)"""
+    def genotype_vcf_to_store(self, ctx, writer, data_path: str, chromosome: int):
+        """one chromosome file -> group chr_{N} (all samples at once); the single-file form of what convert_rank
+        does for a whole rank (the reference's per-(donor, chromosome) method, vcf_to_h5.py:79-140)"""
         from ._lib import BLOSC1      # filter 32001 = hdf5-blosc: Blosc-1 chunk framing
-        stream_fn = stream_fn or _default_stream()
+        from .pipeline import stream_file as stream_fn
         group = f"chr_{chromosome}"
 
         def on_header(names):

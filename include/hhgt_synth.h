@@ -39,6 +39,11 @@ int hhgt_synth_render_mixed(hhgt_ctx *ctx, void *d_text, uint64_t text_cap, cons
                             const uint32_t *d_meta, const uint32_t *d_thr, uint64_t n_variants, uint64_t v_first,
                             const char *contig, int n_samples, uint64_t seed, void *stream);
 
+/* BGZF writer for synthetic shards (BASELINE.md §3 asks for BGZF-compressed inputs; htslib / bgzip are not in the
+ * image): host text -> 0xFF00-byte members deflated at `level` by n_threads threads (0 = hardware concurrency) ->
+ * file, with the empty end-of-file member.  Byte-identical to haplohyped_varawareml_amd.reader.write_bgzf. */
+int hhgt_synth_write_bgzf(const char *path, const void *text, uint64_t nbytes, int level, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

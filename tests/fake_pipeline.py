@@ -24,6 +24,21 @@ def _read_text(path):
     return gzip.decompress(raw) if raw[:2] == b"\x1f\x8b" else raw      # BGZF is multi-member gzip
 
 
+def stream_files(ctx, jobs, sc=64, vc=8192, block_bytes=None, n_threads=0, sites_only=False, fmt=oracle.BLOSC2,
+                 device_inflate=None, on_header=None, on_variants=None, on_columns=None, on_end=None, files_ahead=1):
+    """same interface as pipeline.stream_files"""
+    out = []
+    for i, (path, region) in enumerate(jobs):
+        fs = stream_file(ctx, path, region=region, sc=sc, vc=vc, fmt=fmt,
+                         on_header=(lambda names, i=i: on_header(i, names)) if on_header else None,
+                         on_variants=(lambda a, b, c, i=i: on_variants(i, a, b, c)) if on_variants else None,
+                         on_columns=(lambda g, n, f, i=i: on_columns(i, g, n, f)) if on_columns else None)
+        if on_end:
+            on_end(i, fs)
+        out.append(fs)
+    return out
+
+
 def stream_file(ctx, path, region="", sc=64, vc=8192, block_bytes=None, n_threads=0, sites_only=False, on_columns=None,
                 on_variants=None, on_header=None, compress=True, fmt=oracle.BLOSC2, device_inflate=None):
     t0 = time.perf_counter()

@@ -51,14 +51,14 @@ def test_two_ranks_equal_single_process(tmp_path, golden_dir, fixture_golden):
     one = vcf_to_h5.VCFtoHDF5Converter("c", vcf_dir, str(tmp_path / "one"), samples, 2, 1, n_gpus=1)
     chroms = one.present_chromosomes()
     assert chroms == [4, 7, 22]
-    vcf_to_h5.convert_rank(one, 0, 1, 0, chroms, one.store_path, fake_pipeline.stream_file, fake_pipeline.FakeCtx)
+    vcf_to_h5.convert_rank(one, 0, 1, 0, chroms, one.store_path, fake_pipeline.stream_files, fake_pipeline.FakeCtx)
     # two ranks over gloo
     two = vcf_to_h5.VCFtoHDF5Converter("c", vcf_dir, str(tmp_path / "two"), samples, 2, 1, n_gpus=2)
     cfg = two._config(chroms, 2)
     assert sorted(c for r in cfg["plan"] for c in r) == chroms and all(cfg["plan"])     # a partition, nobody idle
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=vcf_to_h5.worker_entry, args=(r, 2, port, cfg, fake_pipeline.stream_file, fake_pipeline.FakeCtx))
+    procs = [ctx.Process(target=vcf_to_h5.worker_entry, args=(r, 2, port, cfg, fake_pipeline.stream_files, fake_pipeline.FakeCtx))
              for r in range(2)]
     for p in procs:
         p.start()
@@ -91,7 +91,7 @@ def test_failing_rank_fails_the_job(tmp_path, golden_dir, fixture_golden):
     cfg = two._config(two.present_chromosomes(), 2)
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=vcf_to_h5.worker_entry, args=(r, 2, port, cfg, fake_pipeline.stream_file, fake_pipeline.FakeCtx))
+    procs = [ctx.Process(target=vcf_to_h5.worker_entry, args=(r, 2, port, cfg, fake_pipeline.stream_files, fake_pipeline.FakeCtx))
              for r in range(2)]
     for p in procs:
         p.start()

@@ -147,8 +147,8 @@ def test_async_malformed_and_capacity(ctx):
 
 def test_compress_async_needs_the_bound(ctx):
     src = torch.zeros(4 * 65536, dtype=torch.uint8, device=ctx.device)
-    small = torch.empty(1000, dtype=torch.uint8, device=ctx.device)
+    small = torch.empty(4000, dtype=torch.uint8, device=ctx.device)
     with pytest.raises(dev.HhgtError, match="hhgt_compress_bound"):
         ctx.compress(src, 65536, dst=small, sync=False)
     dst, off, total = ctx.compress(src, 65536, dst=small, sync=True)      # the synchronous form sizes exactly
-    assert total <= 1000
+    assert total <= 4000

@@ -101,3 +101,73 @@ def test_bgzf_crc_mismatch_is_an_error(tmp_path, monkeypatch):
         collect(p)
     monkeypatch.setenv("HHGT_BGZF_NO_CRC", "1")
     assert b"".join(collect(p)[0]) == text
+
+
+def test_crc32_matches_zlib():
+    """hhgt_crc32 (PCLMULQDQ folding + table tail) against zlib's crc32 at every alignment / length class"""
+    import ctypes as C
+    import zlib
+    from haplohyped_varawareml_amd import _lib
+    L = _lib.load()
+    L.hhgt_crc32.restype = C.c_uint32
+    L.hhgt_crc32.argtypes = [C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, 70000, dtype=np.uint8)
+    for n in list(range(0, 200)) + [255, 256, 257, 1023, 4096, 65280, 65535, 65536, 69999]:
+        for off in (0, 1, 7):
+            a = np.ascontiguousarray(big[off:off + n])
+            assert L.hhgt_crc32(a.ctypes.data, a.size) == (zlib.crc32(a.tobytes()) & 0xFFFFFFFF), (n, off)
+    z = np.zeros(65536, np.uint8)
+    assert L.hhgt_crc32(z.ctypes.data, z.size) == (zlib.crc32(z.tobytes()) & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("threads,blocks,block_kb", [(1, 2, 1024), (8, 3, 1024), (16, 6, 2048)])
+def test_bgzf_many_blocks_in_flight(tmp_path, threads, blocks, block_kb):
+    """the barrier-free BGZF path: many ring blocks open to the workers at once, held blocks released out of
+    order, every byte and every line boundary intact"""
+    import ctypes as C
+    from haplohyped_varawareml_amd import reader as rd
+    rng = np.random.default_rng(11)
+    lines = [b"chr1\t%d\t.\tA\tC\t" % i + bytes(rng.integers(48, 50, int(rng.integers(10, 9000)), dtype=np.uint8)) + b"\n"
+             for i in range(6000)]
+    text = b"".join(lines)
+    p = str(tmp_path / "x.vcf.gz")
+    rd.write_bgzf(p, text, level=1)
+    L = rd._lib_reader()
+    L.hhgt_reader_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.hhgt_reader_release.argtypes = [C.c_void_p, C.c_int]
+    h = C.c_void_p()
+    rd.check(L.hhgt_reader_open(p.encode(), block_kb << 10, threads, blocks, C.byref(h)))
+    got, held, saw_last = [], [], False
+    while True:
+        ptr, n, tok, last = C.c_void_p(), C.c_uint64(0), C.c_int(-1), C.c_int(0)
+        rd.check(L.hhgt_reader_acquire(h, C.byref(ptr), C.byref(n), C.byref(tok), C.byref(last)))
+        if n.value == 0:
+            break
+        blk = C.string_at(ptr, n.value)
+        assert not saw_last
+        saw_last = bool(last.value)
+        assert blk.endswith(b"\n")
+        got.append(blk)
+        held.append(tok.value)
+        if len(held) >= blocks - 1:                     # keep several blocks, give the newest back first
+            rd.check(L.hhgt_reader_release(h, held.pop()))
+    for t in held:
+        rd.check(L.hhgt_reader_release(h, t))
+    L.hhgt_reader_close(h)
+    assert saw_last and b"".join(got) == text and len(got) > 3
+
+
+def test_bgzf_crc_mismatch_is_reported(tmp_path):
+    from haplohyped_varawareml_amd import reader as rd
+    text = b"".join(b"chr1\t%d\t.\tA\tC\tzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz\n" % i for i in range(20000))
+    p = str(tmp_path / "y.vcf.gz")
+    rd.write_bgzf(p, text, level=6)
+    raw = bytearray(open(p, "rb").read())
+    bsize = raw[16] | (raw[17] << 8)
+    raw[bsize + 1 - 8] ^= 0x55                           # CRC field of the first member
+    open(p, "wb").write(raw)
+    with pytest.raises(Exception, match="CRC32 checksum mismatch"):
+        with rd.VcfReader(p, block_bytes=1 << 20, n_threads=4) as r:
+            for _ in r:
+                pass
