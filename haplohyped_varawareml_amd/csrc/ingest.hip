@@ -18,6 +18,8 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -112,6 +114,8 @@ struct Input {
     hhgt_ingest_stats st;
     double t_first = 0;
     std::string last_run;
+    void *state = nullptr;       // hhgt_ingest::InState of this input (driver thread)
+    bool header_sent = false;
     Input() { memset(&st, 0, sizeof(st)); }
 };
 
@@ -164,8 +168,8 @@ struct OutSlot {
     std::vector<uint64_t> off;
 };
 
-#define N_TEXT_HOST 3
-#define N_TEXT_DEV 3
+#define N_TEXT_HOST 4
+#define N_TEXT_DEV 4
 #define N_RES 4
 #define N_VAR 6
 #define N_DST 3
@@ -196,14 +200,20 @@ struct hhgt_ingest {
     // device-inflate staging
     Staging stg[2];
     DevBuf crc_x2n;
-    // encode state of the current input (driver thread only)
-    hhgt_layout lay;
-    DevBuf G, t_start, t_ref, t_alt, cursor;
-    uint64_t ring_cols = 0, col_bytes = 0, n_sc = 0, chunk_nbytes = 0, kept_per_block = 0, done_cols = 0, host_cursor = 0;
+    // encode state of an input (driver thread only).  Two sets, used alternately: the first blocks of input k+1 are
+    // encoded while the last blocks of input k are still being harvested, so the GPU's queue does not drain at a
+    // file boundary
+    struct InState {
+        hhgt_layout lay;
+        DevBuf G, t_start, t_ref, t_alt, cursor;
+        uint64_t ring_cols = 0, col_bytes = 0, n_sc = 0, chunk_nbytes = 0, kept_per_block = 0, done_cols = 0, host_cursor = 0;
+    } ist[2];
+    uint64_t n_begun = 0;
     struct Res {
         hhgt_encode_result *rec = nullptr;   // pinned
         hipEvent_t ev = nullptr;
         int text_idx = -1;
+        InState *st = nullptr;
     } res[N_RES];
     // slot pools
     VarSlot var[N_VAR];
@@ -215,6 +225,11 @@ struct hhgt_ingest {
     // stages
     BQ<Batch> q_ship, q_out;
     std::thread th_source, th_driver, th_ship;
+    // where the threads spend their time (seconds; HHGT_INGEST_DEBUG=1 prints them at close)
+    struct Times {
+        double src_wait_text = 0, src_work = 0, drv_wait_text = 0, drv_launch = 0, drv_harvest_wait = 0, drv_harvest = 0,
+               drv_begin = 0, ship_wait_ev = 0, ship_copy = 0, ship_wait_out = 0, t_open = 0, t_first_text = 0, t_end = 0;
+    } tm;
     // consumer side: what the previous hhgt_ingest_next handed out
     Batch held;
     bool have_held = false;
@@ -222,6 +237,25 @@ struct hhgt_ingest {
 };
 
 namespace {
+
+struct TraceRec {
+    double t;
+    const char *tag;
+    long long a, b;
+};
+std::mutex g_trace_mu;
+std::vector<TraceRec> g_trace;
+int trace_level()
+{
+    static const int lv = getenv("HHGT_INGEST_DEBUG") ? atoi(getenv("HHGT_INGEST_DEBUG")) : 0;
+    return lv;
+}
+void trace(const char *tag, long long a = 0, long long b = 0)
+{
+    if (trace_level() < 2) return;
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace.push_back({now_s(), tag, a, b});
+}
 
 void fail(hhgt_ingest *g, int code, const char *msg)
 {
@@ -304,13 +338,17 @@ bool is_bgzf_file(const char *path)
 // ---------------------------------------------------------------------------------------------------------------
 bool push_text(hhgt_ingest *g, int ti)
 {
+    trace("src:push_text", ti, (long long)g->text[(size_t)ti].nbytes);
     g->q_text.push(ti);
     return !g->failed.load();
 }
 
 bool take_text(hhgt_ingest *g, int *ti, size_t need)
 {
-    if (!g->free_text.pop(*ti)) return false;
+    const double t0 = now_s();
+    const bool got = g->free_text.pop(*ti);
+    g->tm.src_wait_text += now_s() - t0;
+    if (!got) return false;
     TextBuf &tb = g->text[(size_t)*ti];
     if (tb.cap < need) {   // only when a caller's block is larger than the configured size
         if (tb.d) hipFree(tb.d);
@@ -472,7 +510,13 @@ __global__ void k_count_bad_members(const uint32_t *__restrict__ st, uint64_t n,
 }
 
 // BGZF file inflated on the device: the host walks the member headers and decides the block cuts, the compressed
-// members cross PCIe, one wave per member writes the text (csrc/inflate.hip)
+// members cross PCIe, one wave per member writes the text (csrc/inflate.hip).
+// Per block the source thread: pread()s the next stretch of the file straight into a pinned staging slot (no mapping:
+// read() copies out of the page cache without faulting a page per 4 KiB), walks the member headers there until the
+// block's text budget is used up, inflates the LAST member(s) on the host to learn where the last whole line ends,
+// writes the member tables behind the compressed bytes and queues upload + carry copy + inflate kernels.  The first
+// blocks of an input are small (the GPU starts after ~1 ms of host work), later ones grow to block_bytes (a launch
+// wants >= 10 k members to fill the chip).
 bool run_device_inflate_input(hhgt_ingest *g, Input *in)
 {
     const uint64_t bb = g->o.block_bytes ? g->o.block_bytes : (1ull << 30);
@@ -484,110 +528,153 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
         fail(g, HHGT_ERR_IO, hhgt_last_error());
         return false;
     }
-    const size_t flen = (size_t)st.st_size;
-    const uint8_t *map = flen ? static_cast<const uint8_t *>(mmap(nullptr, flen, PROT_READ, MAP_PRIVATE, fd, 0)) : nullptr;
-    if (flen && map == MAP_FAILED) {
-        close(fd);
-        fail(g, HHGT_ERR_IO, "cannot mmap the BGZF file");
-        return false;
-    }
+    const uint64_t flen = (uint64_t)st.st_size;
     in->st.file_bytes = flen;
     in->is_bgzf = true;
     bool ok = true;
-    std::vector<uint64_t> c_off;
-    std::vector<uint32_t> c_len, isz, crc;
-    {
-        // member table of the whole file (2 ms per 18 k members)
-        uint64_t pos = 0;
-        std::vector<uint64_t> o(1 << 16);
-        std::vector<uint32_t> l(1 << 16), z(1 << 16), c(1 << 16);
-        while (pos < flen) {
-            uint64_t n = 0, used = 0;
-            const int rc = hhgt_bgzf_scan(map + pos, flen - pos, o.size(), o.data(), l.data(), z.data(), c.data(), &n, &used);
-            if (rc != HHGT_OK) {
-                fail(g, rc, hhgt_last_error());
-                ok = false;
-                break;
-            }
-            if (n == 0) break;
-            for (uint64_t i = 0; i < n; ++i) {
-                c_off.push_back(o[i] + pos);
-                c_len.push_back(l[i]);
-                isz.push_back(z[i]);
-                crc.push_back(c[i]);
-            }
-            pos += used;
-        }
-        if (ok && pos != flen) {
-            fail(g, HHGT_ERR_MALFORMED, "bytes behind the last whole BGZF member");
-            ok = false;
-        }
-    }
-    const size_t M = c_off.size();
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     inflateInit2(&zs, -15);
     std::vector<uint8_t> scratch(65536);
-    auto host_inflate = [&](size_t m, uint8_t *dst) -> bool {
+    std::vector<uint64_t> c_off;
+    std::vector<uint32_t> c_len, isz, crc;
+    auto host_inflate = [&](const uint8_t *base, size_t m, uint8_t *dst) -> bool {
         if (inflateReset(&zs) != Z_OK) return false;
-        zs.next_in = const_cast<Bytef *>(map + c_off[m]);
+        zs.next_in = const_cast<Bytef *>(base + c_off[m]);
         zs.avail_in = c_len[m];
         zs.next_out = dst;
         zs.avail_out = isz[m];
         return inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
     };
-    // header: leading members inflated on the host until the '#' lines are complete
-    if (ok) {
-        std::vector<uint8_t> head;
-        bool have = false;
-        for (size_t m = 0; m < M && head.size() < (256u << 20); ++m) {
-            const size_t at = head.size();
-            head.resize(at + isz[m]);
-            if (isz[m] && !host_inflate(m, head.data() + at)) {
-                fail(g, HHGT_ERR_IO, "inflate failed (header members)");
-                ok = false;
-                break;
-            }
-            size_t hb;
-            uint64_t S;
-            if (parse_header_text(head.data(), head.size(), &hb, &S, m + 1 == M)) {
-                have = set_header(g, in, head.data(), head.size(), m + 1 == M);
-                break;
-            }
+    auto pread_all = [&](uint8_t *dst, size_t n, uint64_t off) -> bool {
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t k = pread(fd, dst + got, n - got, (off_t)(off + got));
+            if (k <= 0) return false;
+            got += (size_t)k;
         }
-        if (ok && !have) {
-            if (!g->failed.load()) {
-                hhgt_set_error("%s: no #CHROM header line", in->path.c_str());
-                fail(g, HHGT_ERR_MALFORMED, hhgt_last_error());
-            }
-            ok = false;
-        }
-    }
-    size_t m0 = 0;
-    uint64_t carry = 0;
+        return true;
+    };
+    uint64_t fpos = 0;          // file offset of the first member not yet in a block
+    uint64_t carry = 0;         // bytes of the previous block behind its last newline
     int prev_ti = -1;
     uint64_t prev_cut = 0;
     bool first = true;
     int sidx = 0;
-    while (ok && m0 < M) {
-        // members of this block
-        uint64_t total = 0;
-        size_t m1 = m0;
-        while (m1 < M && carry + total + isz[m1] <= bb) total += isz[m1++];
-        if (m1 == m0) {
+    double ratio = 24.0;        // text bytes per file byte, refined as blocks go by
+    uint64_t budget = bb < (96ull << 20) ? bb : (96ull << 20);   // text budget of the first block
+    uint64_t member_index = 0;
+    if (flen == 0) {
+        fail(g, HHGT_ERR_MALFORMED, "empty file (no VCF header)");
+        ok = false;
+    }
+    while (ok && fpos < flen) {
+        Staging &sg = g->stg[sidx];
+        sidx ^= 1;
+        if (sg.used) hipEventSynchronize(sg.done);   // the inflate that read this staging slot two blocks ago
+        // stretch of the file to look at: what the budget should need, plus slack; at least one whole member
+        uint64_t want = (uint64_t)((double)budget / ratio * 1.15) + (256u << 10);
+        if (want > flen - fpos) want = flen - fpos;
+        const size_t tab_room = (size_t)(want / 26 + 2) * 28 + 64;   // tables live behind the compressed bytes (a member is >= 26 bytes)
+        if (sg.h.ensure((size_t)want + 64 + tab_room) != HHGT_OK) {
+            fail(g, HHGT_ERR_HIP, hhgt_last_error());
+            ok = false;
+            break;
+        }
+        {
+            // one thread copies ~5 GB/s out of the page cache; a 1 GiB text block needs ~40 MB of file
+            const size_t piece = 2u << 20;
+            const int nth = want > 4 * piece ? 4 : 1;
+            std::atomic<size_t> next{0};
+            std::atomic<bool> rd_ok{true};
+            auto work = [&] {
+                for (;;) {
+                    const size_t o = next.fetch_add(piece);
+                    if (o >= want) break;
+                    const size_t n = want - o < piece ? (size_t)(want - o) : piece;
+                    if (!pread_all(sg.h.p + o, n, fpos + o)) rd_ok.store(false);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int i = 1; i < nth; ++i) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+            if (!rd_ok.load()) {
+                fail(g, HHGT_ERR_IO, "read failed");
+                ok = false;
+                break;
+            }
+        }
+        // member table of the stretch, cut at the text budget
+        const size_t max_m = (size_t)(want / 26 + 2);
+        c_off.resize(max_m);
+        c_len.resize(max_m);
+        isz.resize(max_m);
+        crc.resize(max_m);
+        uint64_t nm64 = 0, used = 0;
+        const int rc = hhgt_bgzf_scan(sg.h.p, want, max_m, c_off.data(), c_len.data(), isz.data(), crc.data(), &nm64, &used);
+        if (rc != HHGT_OK) {
+            fail(g, rc, hhgt_last_error());
+            ok = false;
+            break;
+        }
+        if (nm64 == 0) {
+            if (want == flen - fpos) fail(g, HHGT_ERR_MALFORMED, "bytes behind the last whole BGZF member");
+            else fail(g, HHGT_ERR_IO, "a BGZF member larger than the staging stretch");
+            ok = false;
+            break;
+        }
+        size_t nm = 0;
+        uint64_t total = 0, consumed = 0;
+        while (nm < nm64 && carry + total + isz[nm] <= budget) {
+            total += isz[nm];
+            consumed = c_off[nm] + c_len[nm] + 8;   // payload + CRC32 + ISIZE
+            ++nm;
+        }
+        if (nm == 0) {
             fail(g, HHGT_ERR_IO, "a line is longer than the text block: raise block_bytes");
             ok = false;
             break;
         }
-        const bool last = m1 == M;
+        const bool last = fpos + consumed >= flen;
+        if (first) {
+            // header: leading members inflated on the host until the '#' lines are complete
+            std::vector<uint8_t> head;
+            bool have = false;
+            for (size_t m = 0; m < nm64 && head.size() < (256u << 20); ++m) {
+                const size_t at = head.size();
+                head.resize(at + isz[m]);
+                if (isz[m] && !host_inflate(sg.h.p, m, head.data() + at)) {
+                    fail(g, HHGT_ERR_IO, "inflate failed (header members)");
+                    ok = false;
+                    break;
+                }
+                size_t hb;
+                uint64_t S;
+                const bool eof = fpos + c_off[m] + c_len[m] + 8 >= flen;
+                if (parse_header_text(head.data(), head.size(), &hb, &S, eof)) {
+                    have = set_header(g, in, head.data(), head.size(), eof);
+                    break;
+                }
+            }
+            if (!ok) break;
+            if (!have) {
+                if (!g->failed.load()) {
+                    hhgt_set_error("%s: no #CHROM header line", in->path.c_str());
+                    fail(g, HHGT_ERR_MALFORMED, hhgt_last_error());
+                }
+                ok = false;
+                break;
+            }
+        }
         // bytes behind the last newline move to the next block: the last member(s) are inflated here to find it
         uint64_t tail = 0;
         if (!last) {
             bool found = false;
-            for (size_t m = m1; m > m0 && !found; --m) {
+            for (size_t m = nm; m > 0 && !found; --m) {
                 const size_t mm = m - 1;
                 if (isz[mm] == 0) continue;
-                if (!host_inflate(mm, scratch.data())) {
+                if (!host_inflate(sg.h.p, mm, scratch.data())) {
                     fail(g, HHGT_ERR_IO, "inflate failed (block tail)");
                     ok = false;
                     break;
@@ -613,34 +700,32 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
             break;
         }
         TextBuf &tb = g->text[(size_t)ti];
-        Staging &sg = g->stg[sidx];
-        sidx ^= 1;
-        if (sg.used) hipEventSynchronize(sg.done);   // the inflate that read this staging slot two blocks ago
-        const size_t nm = m1 - m0;
-        const uint64_t a = c_off[m0], b = c_off[m1 - 1] + c_len[m1 - 1];
-        const size_t comp_bytes = ((size_t)(b - a) + 3) / 4 * 4 + 4;
         // staging layout: [compressed bytes | comp_off u64 | out_off u64 | comp_len u32 | isize u32 | crc u32]
+        const size_t comp_bytes = ((size_t)consumed + 3) / 4 * 4 + 4;
         const size_t o_coff = (comp_bytes + 7) & ~(size_t)7, o_ooff = o_coff + nm * 8, o_clen = o_ooff + nm * 8,
                      o_isz = o_clen + nm * 4, o_crc = o_isz + nm * 4, stg_bytes = o_crc + nm * 4;
-        if (sg.h.ensure(stg_bytes) != HHGT_OK || sg.d.ensure(stg_bytes) != HHGT_OK || tb.status.ensure(nm * 4) != HHGT_OK ||
-            tb.bad.ensure(8) != HHGT_OK) {
+        if (stg_bytes > sg.h.cap) {
+            fail(g, HHGT_ERR_IO, "ingest: staging slot too small for the member tables");
+            ok = false;
+            break;
+        }
+        if (sg.d.ensure(stg_bytes) != HHGT_OK || tb.status.ensure(nm * 4) != HHGT_OK || tb.bad.ensure(8) != HHGT_OK) {
             fail(g, HHGT_ERR_HIP, hhgt_last_error());
             ok = false;
             break;
         }
-        memcpy(sg.h.p, map + a, (size_t)(b - a));
-        memset(sg.h.p + (b - a), 0, comp_bytes - (size_t)(b - a));
+        memset(sg.h.p + consumed, 0, comp_bytes - (size_t)consumed);   // the kernel reads whole dwords
         uint64_t *hc = reinterpret_cast<uint64_t *>(sg.h.p + o_coff), *ho = reinterpret_cast<uint64_t *>(sg.h.p + o_ooff);
         uint32_t *hl = reinterpret_cast<uint32_t *>(sg.h.p + o_clen), *hz = reinterpret_cast<uint32_t *>(sg.h.p + o_isz),
                  *hr = reinterpret_cast<uint32_t *>(sg.h.p + o_crc);
         uint64_t oo = carry;
         for (size_t i = 0; i < nm; ++i) {
-            hc[i] = c_off[m0 + i] - a;
+            hc[i] = c_off[i];
             ho[i] = oo;
-            hl[i] = c_len[m0 + i];
-            hz[i] = isz[m0 + i];
-            hr[i] = crc[m0 + i];
-            oo += isz[m0 + i];
+            hl[i] = c_len[i];
+            hz[i] = isz[i];
+            hr[i] = crc[i];
+            oo += isz[i];
         }
         uint8_t *dd = sg.d.as<uint8_t>();
         hipError_t e = hipMemcpyAsync(dd, sg.h.p, stg_bytes, hipMemcpyHostToDevice, g->s_inf);
@@ -652,12 +737,12 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
             ok = false;
             break;
         }
-        const int rc = launch_inflate(dd, comp_bytes, reinterpret_cast<const uint64_t *>(dd + o_coff),
-                                      reinterpret_cast<const uint32_t *>(dd + o_clen), reinterpret_cast<const uint64_t *>(dd + o_ooff),
-                                      reinterpret_cast<const uint32_t *>(dd + o_isz), nm, tb.d, tb.cap, tb.status.as<uint32_t>(),
-                                      reinterpret_cast<const uint32_t *>(dd + o_crc), g->crc_x2n.as<uint32_t>(), g->s_inf);
-        if (rc != HHGT_OK) {
-            fail(g, rc, hhgt_last_error());
+        const int rc2 = launch_inflate(dd, comp_bytes, reinterpret_cast<const uint64_t *>(dd + o_coff),
+                                       reinterpret_cast<const uint32_t *>(dd + o_clen), reinterpret_cast<const uint64_t *>(dd + o_ooff),
+                                       reinterpret_cast<const uint32_t *>(dd + o_isz), nm, tb.d, tb.cap, tb.status.as<uint32_t>(),
+                                       reinterpret_cast<const uint32_t *>(dd + o_crc), g->crc_x2n.as<uint32_t>(), g->s_inf);
+        if (rc2 != HHGT_OK) {
+            fail(g, rc2, hhgt_last_error());
             ok = false;
             break;
         }
@@ -678,21 +763,18 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
         tb.first = first;
         tb.last = last;
         tb.n_members = nm;
-        tb.first_member = m0;
+        tb.first_member = member_index;
+        member_index += nm;
         first = false;
         prev_ti = ti;
         prev_cut = tb.nbytes;
         carry = tail;
-        m0 = m1;
+        fpos += consumed;
+        if (total && consumed) ratio = 0.5 * ratio + 0.5 * ((double)total / (double)consumed);
+        budget = budget * 4 < bb ? budget * 4 : bb;
         if (!push_text(g, ti)) ok = false;
     }
-    if (ok && M == 0) {
-        fail(g, HHGT_ERR_MALFORMED, "empty file (no VCF header)");
-        ok = false;
-    }
     inflateEnd(&zs);
-    // the mapping is read by memcpy only (staging), so it can go as soon as the loop is over
-    if (map) munmap(const_cast<uint8_t *>(map), flen);
     close(fd);
     return ok;
 }
@@ -744,40 +826,42 @@ void source_main(hhgt_ingest *g)
 // ---------------------------------------------------------------------------------------------------------------
 bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
 {
+    hhgt_ingest::InState *X = &g->ist[g->n_begun++ & 1u];
+    in->state = X;
     const uint64_t S = in->S;
     const int32_t sc = g->o.sc, vc = g->o.vc;
     // a kept line holds S sample columns of at least two bytes behind nine fixed columns
-    g->kept_per_block = block_bytes / (2 * S + 16) + 2;
-    const uint64_t W = g->kept_per_block / (uint64_t)vc + 2;   // chunk columns one block can touch
-    g->ring_cols = 2 * W + 6;
-    memset(&g->lay, 0, sizeof(g->lay));
-    g->lay.n_samples = (int32_t)S;
-    g->lay.sc = sc;
-    g->lay.vc = vc;
-    g->lay.ring = (int32_t)g->ring_cols;
-    g->lay.v_capacity = g->ring_cols * (uint64_t)vc;
-    g->n_sc = S ? (S + (uint64_t)sc - 1) / (uint64_t)sc : 0;
-    g->chunk_nbytes = (uint64_t)sc * (uint64_t)vc * 2;
-    g->col_bytes = g->n_sc * g->chunk_nbytes;
-    const uint64_t gbytes = hhgt_layout_bytes(&g->lay);
-    G_TRY(g->G.ensure((size_t)(gbytes ? gbytes : 16)));
-    G_TRY(g->t_start.ensure((size_t)g->lay.v_capacity * 4));
-    G_TRY(g->t_ref.ensure((size_t)g->lay.v_capacity));
-    G_TRY(g->t_alt.ensure((size_t)g->lay.v_capacity));
-    G_TRY(g->cursor.ensure(8));
+    X->kept_per_block = block_bytes / (2 * S + 16) + 2;
+    const uint64_t W = X->kept_per_block / (uint64_t)vc + 2;   // chunk columns one block can touch
+    X->ring_cols = 2 * W + 6;
+    memset(&X->lay, 0, sizeof(X->lay));
+    X->lay.n_samples = (int32_t)S;
+    X->lay.sc = sc;
+    X->lay.vc = vc;
+    X->lay.ring = (int32_t)X->ring_cols;
+    X->lay.v_capacity = X->ring_cols * (uint64_t)vc;
+    X->n_sc = S ? (S + (uint64_t)sc - 1) / (uint64_t)sc : 0;
+    X->chunk_nbytes = (uint64_t)sc * (uint64_t)vc * 2;
+    X->col_bytes = X->n_sc * X->chunk_nbytes;
+    const uint64_t gbytes = hhgt_layout_bytes(&X->lay);
+    G_TRY(X->G.ensure((size_t)(gbytes ? gbytes : 16)));
+    G_TRY(X->t_start.ensure((size_t)X->lay.v_capacity * 4));
+    G_TRY(X->t_ref.ensure((size_t)X->lay.v_capacity));
+    G_TRY(X->t_alt.ensure((size_t)X->lay.v_capacity));
+    G_TRY(X->cursor.ensure(8));
     // sample padding rows (S .. round_up(S, sc)) are never written by the encoder: zero once per input
-    if (gbytes) G_HIP(hipMemsetAsync(g->G.p, 0, (size_t)gbytes, g->s_main));
-    G_HIP(hipMemsetAsync(g->cursor.p, 0, 8, g->s_main));
-    g->done_cols = 0;
-    g->host_cursor = 0;
+    if (gbytes) G_HIP(hipMemsetAsync(X->G.p, 0, (size_t)gbytes, g->s_main));
+    G_HIP(hipMemsetAsync(X->cursor.p, 0, 8, g->s_main));
+    X->done_cols = 0;
+    X->host_cursor = 0;
     // batch buffers.  They may still be in use by batches of the previous input that are on their way out, so when
     // one has to grow (this input has more samples, or is the first) every slot is collected first — the shipper and
     // the consumer give them back as they go — and returned to the pools afterwards.
     const uint64_t max_cols = W + 2;
-    const size_t need_d = (size_t)(max_cols * g->n_sc * (g->chunk_nbytes + 32) + 64), need_off = (size_t)((max_cols * g->n_sc + 1) * 8);
+    const size_t need_d = (size_t)(max_cols * X->n_sc * (X->chunk_nbytes + 32) + 64), need_off = (size_t)((max_cols * X->n_sc + 1) * 8);
     bool grow = false;
     for (auto &d : g->dst) grow = grow || d.d.cap < need_d || d.off.cap < need_off || d.h_off.cap < need_off;
-    for (auto &v : g->var) grow = grow || v.start.cap < (size_t)g->kept_per_block * 4 || v.ref.cap < (size_t)g->kept_per_block;
+    for (auto &v : g->var) grow = grow || v.start.cap < (size_t)X->kept_per_block * 4 || v.ref.cap < (size_t)X->kept_per_block;
     if (grow) {
         int tmp;
         for (int i = 0; i < N_DST; ++i)
@@ -790,18 +874,15 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
             G_TRY(d.h_off.ensure(need_off));
         }
         for (auto &v : g->var) {
-            G_TRY(v.start.ensure((size_t)g->kept_per_block * 4));
-            G_TRY(v.ref.ensure((size_t)g->kept_per_block));
-            G_TRY(v.alt.ensure((size_t)g->kept_per_block));
+            G_TRY(v.start.ensure((size_t)X->kept_per_block * 4));
+            G_TRY(v.ref.ensure((size_t)X->kept_per_block));
+            G_TRY(v.alt.ensure((size_t)X->kept_per_block));
         }
         for (int i = 0; i < N_DST; ++i) g->free_dst.push(i);
         for (int i = 0; i < N_VAR; ++i) g->free_var.push(i);
     }
     in->t_first = now_s();
-    Batch b;
-    b.kind = B_HEADER;
-    b.in = in;
-    g->q_ship.push(b);
+    in->header_sent = false;   // announced by the first harvest of this input: behind the previous input's last events
     return true;
 }
 
@@ -827,20 +908,21 @@ bool get_event(hhgt_ingest *g, hipEvent_t *ev)
 // completed columns [c0, c1) -> compress batches (one per contiguous run of ring slots)
 bool queue_columns(hhgt_ingest *g, Input *in, uint64_t c0, uint64_t c1)
 {
+    hhgt_ingest::InState *X = static_cast<hhgt_ingest::InState *>(in->state);
     while (c0 < c1) {
-        const uint64_t slot = c0 % g->ring_cols;
-        const uint64_t n = (c1 - c0) < (g->ring_cols - slot) ? (c1 - c0) : (g->ring_cols - slot);
+        const uint64_t slot = c0 % X->ring_cols;
+        const uint64_t n = (c1 - c0) < (X->ring_cols - slot) ? (c1 - c0) : (X->ring_cols - slot);
         Batch b;
         b.kind = B_COLUMNS;
         b.in = in;
         b.first_col = c0;
         b.n_cols = n;
-        b.n_chunks = n * g->n_sc;
-        b.raw_bytes = n * g->col_bytes;
+        b.n_chunks = n * X->n_sc;
+        b.raw_bytes = n * X->col_bytes;
         if (!g->free_dst.pop(b.dst_slot) || !get_event(g, &b.ev)) return false;
         DstSlot &d = g->dst[(size_t)b.dst_slot];
         const int bs = g->o.blocksize;
-        G_TRY(hhgt_compress_chunks(g->ctx, g->G.as<uint8_t>() + slot * g->col_bytes, b.n_chunks, g->chunk_nbytes, g->o.typesize, bs,
+        G_TRY(hhgt_compress_chunks(g->ctx, X->G.as<uint8_t>() + slot * X->col_bytes, b.n_chunks, X->chunk_nbytes, g->o.typesize, bs,
                                    g->o.format, d.d.p, d.d.cap, d.off.as<uint64_t>(), nullptr, g->s_main));
         G_HIP(hipMemcpyAsync(d.h_off.p, d.off.p, (size_t)((b.n_chunks + 1) * 8), hipMemcpyDeviceToHost, g->s_main));
         G_HIP(hipEventRecord(b.ev, g->s_main));
@@ -851,11 +933,32 @@ bool queue_columns(hhgt_ingest *g, Input *in, uint64_t c0, uint64_t c1)
 }
 
 // look at the result record of an encoded block (its event has been waited for)
+bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r);
 bool harvest(hhgt_ingest *g, hhgt_ingest::Res &r)
 {
+    const double t0 = now_s();
     G_HIP(hipEventSynchronize(r.ev));
+    const double t1 = now_s();
+    trace("drv:encode_done", r.text_idx);
+    const bool ok = harvest_body(g, r);
+    trace("drv:harvested");
+    g->tm.drv_harvest_wait += t1 - t0;
+    g->tm.drv_harvest += now_s() - t1;
+    return ok;
+}
+
+bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
+{
     TextBuf &tb = g->text[(size_t)r.text_idx];
     Input *in = tb.in;
+    hhgt_ingest::InState *X = r.st;
+    if (!in->header_sent) {
+        Batch h;
+        h.kind = B_HEADER;
+        h.in = in;
+        g->q_ship.push(h);
+        in->header_sent = true;
+    }
     const hhgt_encode_result rec = *r.rec;
     if (in->dev_inflate && *tb.h_bad) {
         // which member, and why: only now is the per-member status worth copying
@@ -886,7 +989,7 @@ bool harvest(hhgt_ingest *g, hhgt_ingest::Res &r)
     const bool last = tb.last;
     g->free_text.push(r.text_idx);   // the text has been consumed: the source may overwrite the buffer
     r.text_idx = -1;
-    g->host_cursor = b;
+    X->host_cursor = b;
     in->st.n_kept = b;
     if (b > a || rec.stats.n_chrom_runs) {
         Batch v;
@@ -896,9 +999,9 @@ bool harvest(hhgt_ingest *g, hhgt_ingest::Res &r)
         v.n_variants = b - a;
         if (!g->free_var.pop(v.var_slot) || !get_event(g, &v.ev)) return false;
         VarSlot &vs = g->var[(size_t)v.var_slot];
-        const uint64_t cap = g->lay.v_capacity;
-        if (!ring_d2h(g, vs.start.p, g->t_start.p, a, b, cap, 4) || !ring_d2h(g, vs.ref.p, g->t_ref.p, a, b, cap, 1) ||
-            !ring_d2h(g, vs.alt.p, g->t_alt.p, a, b, cap, 1))
+        const uint64_t cap = X->lay.v_capacity;
+        if (!ring_d2h(g, vs.start.p, X->t_start.p, a, b, cap, 4) || !ring_d2h(g, vs.ref.p, X->t_ref.p, a, b, cap, 1) ||
+            !ring_d2h(g, vs.alt.p, X->t_alt.p, a, b, cap, 1))
             return false;
         for (uint64_t i = 0; i < rec.stats.n_chrom_runs; ++i) {
             const std::string name(rec.run_names[i], strnlen(rec.run_names[i], 31));
@@ -914,15 +1017,15 @@ bool harvest(hhgt_ingest *g, hhgt_ingest::Res &r)
     }
     if (in->S) {
         const uint64_t done = b / (uint64_t)g->o.vc;
-        if (done > g->done_cols) {
-            if (!queue_columns(g, in, g->done_cols, done)) return false;
-            g->done_cols = done;
+        if (done > X->done_cols) {
+            if (!queue_columns(g, in, X->done_cols, done)) return false;
+            X->done_cols = done;
         }
         if (last && b % (uint64_t)g->o.vc) {
             // the open column: zero behind the cursor, frame it
-            G_TRY(hhgt_pad_tail_cursor(g->ctx, &g->lay, g->cursor.as<uint64_t>(), g->G.p, g->s_main));
-            if (!queue_columns(g, in, g->done_cols, g->done_cols + 1)) return false;
-            g->done_cols += 1;
+            G_TRY(hhgt_pad_tail_cursor(g->ctx, &X->lay, X->cursor.as<uint64_t>(), X->G.p, g->s_main));
+            if (!queue_columns(g, in, X->done_cols, X->done_cols + 1)) return false;
+            X->done_cols += 1;
         }
     }
     if (last) {
@@ -941,38 +1044,54 @@ void driver_main(hhgt_ingest *g)
     int next_res = 0;
     for (;;) {
         int ti;
-        if (!g->q_text.pop(ti)) break;
+        const double tw = now_s();
+        const bool got = g->q_text.pop(ti);
+        g->tm.drv_wait_text += now_s() - tw;
+        if (!got) break;
         if (ti < 0) break;   // end of inputs
+        if (g->tm.t_first_text == 0) g->tm.t_first_text = now_s();
         TextBuf &tb = g->text[(size_t)ti];
         Input *in = tb.in;
         auto drv = [&]() -> bool {
+            const double tb0 = now_s();
             if (tb.first && !begin_input(g, in, tb.cap)) return false;
+            g->tm.drv_begin += now_s() - tb0;
             if ((int)pending.size() >= N_RES - 1) {
                 if (!harvest(g, g->res[pending.front()])) return false;
                 pending.pop_front();
             }
             hhgt_ingest::Res &r = g->res[next_res];
+            hhgt_ingest::InState *X = static_cast<hhgt_ingest::InState *>(in->state);
+            r.st = X;
+            const double tl0 = now_s();
+            trace("drv:encode_launch", ti, (long long)tb.nbytes);
             G_HIP(hipStreamWaitEvent(g->s_main, tb.ready, 0));
             // a line count cannot exceed 1024 per 16 KiB region without tripping the density check, so this bound
             // always holds and the asynchronous encode never has to be repeated
             const uint64_t n_regions = (tb.nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION;
             const uint64_t max_lines = n_regions * INDEX_CAP;
-            G_TRY(hhgt_encode_text_async(g->ctx, tb.d, tb.nbytes, in->region.c_str(), &g->lay, g->cursor.as<uint64_t>(),
-                                         (uint32_t)(max_lines > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : max_lines), g->G.p,
-                                         g->t_start.as<uint32_t>(), nullptr, g->t_ref.as<uint8_t>(), g->t_alt.as<uint8_t>(), r.rec,
+            G_TRY(hhgt_encode_text_async(g->ctx, tb.d, tb.nbytes, in->region.c_str(), &X->lay, X->cursor.as<uint64_t>(),
+                                         (uint32_t)(max_lines > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : max_lines), X->G.p,
+                                         X->t_start.as<uint32_t>(), nullptr, X->t_ref.as<uint8_t>(), X->t_alt.as<uint8_t>(), r.rec,
                                          g->s_main));
             G_HIP(hipEventRecord(r.ev, g->s_main));
             r.text_idx = ti;
             pending.push_back(next_res);
             next_res = (next_res + 1) % N_RES;
-            // one block behind: the GPU has the encode above queued while the host looks at the previous result
-            while (pending.size() > 1 || (tb.last && !pending.empty())) {
+            g->tm.drv_launch += now_s() - tl0;
+            // one block behind: the GPU has the encode above queued while the host looks at the previous result.  The
+            // last block of an input is only drained at once when nothing else is waiting to be queued.
+            while (pending.size() > 1 || (tb.last && !pending.empty() && g->q_text.size() == 0)) {
                 if (!harvest(g, g->res[pending.front()])) return false;
                 pending.pop_front();
             }
             return true;
         };
         if (!drv()) break;
+    }
+    while (!g->failed.load() && !pending.empty()) {
+        if (!harvest(g, g->res[pending.front()])) break;
+        pending.pop_front();
     }
     if (!g->failed.load()) {
         Batch e;
@@ -992,6 +1111,7 @@ void ship_main(hhgt_ingest *g)
     for (;;) {
         Batch b;
         if (!g->q_ship.pop(b)) break;
+        const double ts0 = now_s();
         if (b.kind == B_VARIANTS) {
             if (hipEventSynchronize(b.ev) != hipSuccess) {
                 fail(g, HHGT_ERR_HIP, "ingest: variant table copy failed");
@@ -1006,10 +1126,15 @@ void ship_main(hhgt_ingest *g)
             }
             g->free_ev.push(b.ev);
             b.ev = nullptr;
+            g->tm.ship_wait_ev += now_s() - ts0;
+            trace("ship:compress_done", (long long)b.n_cols);
             DstSlot &d = g->dst[(size_t)b.dst_slot];
             const uint64_t *off = reinterpret_cast<const uint64_t *>(d.h_off.p);
             b.framed_bytes = off[b.n_chunks];
+            const double tso = now_s();
             if (!g->free_out.pop(b.out_slot)) break;
+            g->tm.ship_wait_out += now_s() - tso;
+            const double tsc = now_s();
             OutSlot &o = g->out[(size_t)b.out_slot];
             if (o.h.ensure((size_t)b.framed_bytes + 64) != HHGT_OK) {
                 fail(g, HHGT_ERR_HIP, hhgt_last_error());
@@ -1021,14 +1146,28 @@ void ship_main(hhgt_ingest *g)
                 fail(g, HHGT_ERR_HIP, "ingest: copy of the framed chunks failed");
                 break;
             }
+            g->tm.ship_copy += now_s() - tsc;
+            trace("ship:copied", (long long)b.framed_bytes, (long long)b.n_cols);
             g->free_dst.push(b.dst_slot);
             b.dst_slot = -1;
             b.in->st.raw_bytes += b.raw_bytes;
             b.in->st.compressed_bytes += b.framed_bytes;
         } else if (b.kind == B_INPUT_END) {
             b.in->st.seconds = now_s() - b.in->t_first;
+            static const bool dbg = getenv("HHGT_INGEST_DEBUG") != nullptr;
+            if (dbg) {   // per input, then reset (the threads' counters are only read here: a development aid)
+                auto &t = g->tm;
+                fprintf(stderr,
+                        "[hhgt ingest] input %d: %.1f ms | source: wait for a text buffer %.1f | driver: wait for text %.1f, begin_input %.1f, "
+                        "encode launch %.1f, harvest wait %.1f, harvest work %.1f | shipper: wait for compress %.1f, wait for an out slot %.1f, "
+                        "copy %.1f (ms)\n",
+                        b.in->index, b.in->st.seconds * 1e3, t.src_wait_text * 1e3, t.drv_wait_text * 1e3, t.drv_begin * 1e3, t.drv_launch * 1e3,
+                        t.drv_harvest_wait * 1e3, t.drv_harvest * 1e3, t.ship_wait_ev * 1e3, t.ship_wait_out * 1e3, t.ship_copy * 1e3);
+                t = hhgt_ingest::Times();
+            }
         }
         const int kind = b.kind;
+        if (kind == B_END) g->tm.t_end = now_s();
         g->q_out.push(b);
         if (kind == B_END) break;
     }
@@ -1110,6 +1249,7 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
         hhgt_ingest_close(g);
         return rc;
     }
+    g->tm.t_open = now_s();
     g->th_source = std::thread(source_main, g);
     g->th_driver = std::thread(driver_main, g);
     g->th_ship = std::thread(ship_main, g);
@@ -1134,6 +1274,7 @@ static int add_input(hhgt_ingest *g, std::unique_ptr<Input> in)
 extern "C" int hhgt_ingest_add_file(hhgt_ingest *g, const char *path, const char *region)
 {
     if (!g || !path) return HHGT_ERR_ARG;
+    trace("add_file");
     if (access(path, R_OK) != 0) {
         hhgt_set_error("cannot open %s", path);
         return HHGT_ERR_IO;
@@ -1241,6 +1382,12 @@ extern "C" void hhgt_ingest_close(hhgt_ingest *g)
     if (g->th_source.joinable()) g->th_source.join();
     if (g->th_driver.joinable()) g->th_driver.join();
     if (g->th_ship.joinable()) g->th_ship.join();
+    if (trace_level() >= 2) {
+        std::lock_guard<std::mutex> lk(g_trace_mu);
+        const double t0 = g_trace.empty() ? 0 : g_trace[0].t;
+        for (auto &r : g_trace) fprintf(stderr, "[trace] %9.3f ms  %-20s %lld %lld\n", (r.t - t0) * 1e3, r.tag, r.a, r.b);
+        g_trace.clear();
+    }
     for (hipStream_t s : {g->s_main, g->s_copy, g->s_inf, g->s_out})
         if (s) {
             hipStreamSynchronize(s);
@@ -1259,7 +1406,8 @@ extern "C" void hhgt_ingest_close(hhgt_ingest *g)
         if (s.done) hipEventDestroy(s.done);
     }
     g->crc_x2n.release();
-    for (DevBuf *b : {&g->G, &g->t_start, &g->t_ref, &g->t_alt, &g->cursor}) b->release();
+    for (auto &x : g->ist)
+        for (DevBuf *b : {&x.G, &x.t_start, &x.t_ref, &x.t_alt, &x.cursor}) b->release();
     for (auto &r : g->res) {
         if (r.rec) hipHostFree(r.rec);
         if (r.ev) hipEventDestroy(r.ev);

@@ -22,6 +22,9 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <condition_variable>
@@ -124,6 +127,45 @@ extern "C" void hhgt_reader_trim_pool(void)
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto &e : g_pool) hipHostFree(e.second);
     g_pool.clear();
+}
+
+// CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool
+// shows 256 hardware threads and grants 16 CPUs' worth of time: 96 inflate threads on it only fight each other)
+extern "C" int hhgt_effective_cpus(void)
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int k = CPU_COUNT(&set);
+        if (k > 0 && (n <= 0 || k < n)) n = k;
+    }
+    const char *files[] = {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"};
+    for (int f = 0; f < 2; ++f) {
+        FILE *fp = fopen(files[f], "r");
+        if (!fp) continue;
+        char a[64] = "", b[64] = "";
+        const int got = fscanf(fp, "%63s %63s", a, b);
+        fclose(fp);
+        long long quota = -1, period = 100000;
+        if (f == 0) {
+            if (got >= 1 && strcmp(a, "max") != 0) quota = atoll(a);
+            if (got >= 2) period = atoll(b);
+        } else {
+            if (got >= 1) quota = atoll(a);
+            FILE *pp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (pp) {
+                if (fscanf(pp, "%63s", b) == 1) period = atoll(b);
+                fclose(pp);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            const int k = (int)((quota + period - 1) / period);
+            if (k > 0 && (n <= 0 || k < n)) n = k;
+        }
+        break;
+    }
+    return n > 0 ? n : 1;
 }
 
 static bool looks_bgzf(const uint8_t *p, size_t n)
@@ -668,11 +710,11 @@ extern "C" int hhgt_reader_open(const char *path, uint64_t block_bytes, int n_th
         r->free_.push_back(i);
     }
     if (r->is_bgzf || !r->is_gzip) {
-        unsigned hw = std::thread::hardware_concurrency();
-        // BGZF default: one worker per physical-core-ish (half the hardware threads), at most 96; HHGT_READER_THREADS
+        // BGZF default: one worker per CPU the process may use (hhgt_effective_cpus), at most 96; HHGT_READER_THREADS
         // or the n_threads argument override.  Uncompressed input: 16 pread threads saturate the page cache copy.
         const char *e = getenv("HHGT_READER_THREADS");
-        int nt = n_threads > 0 ? n_threads : (e && atoi(e) > 0 ? atoi(e) : (hw ? (int)(hw / 2 < 96 ? (hw / 2 ? hw / 2 : 1) : 96) : 4));
+        const int eff = hhgt_effective_cpus();
+        int nt = n_threads > 0 ? n_threads : (e && atoi(e) > 0 ? atoi(e) : (eff < 96 ? eff : 96));
         if (nt > 192) nt = 192;
         if (!r->is_bgzf && nt > 16) nt = 16;
         for (int i = 0; i < nt; ++i) r->workers.emplace_back(worker_main, r);

@@ -44,6 +44,9 @@ int hhgt_reader_next(hhgt_reader *r, const void **host_ptr, uint64_t *nbytes);
 int hhgt_reader_acquire(hhgt_reader *r, const void **host_ptr, uint64_t *nbytes, int *token, int *is_last);
 int hhgt_reader_release(hhgt_reader *r, int token);
 
+/* CPUs this process may use: affinity mask capped by the cgroup CPU quota (the reader's default thread count) */
+int hhgt_effective_cpus(void);
+
 /* Closed readers keep up to 32 pinned ring blocks for the next hhgt_reader_open (pinning memory is slow and a
  * converter opens one reader per chromosome file); this frees them. */
 void hhgt_reader_trim_pool(void);

@@ -158,7 +158,7 @@ def test_errors_surface(ctx, tmp_path):
         with pytest.raises(dev.HhgtError, match="CRC"):
             run_engine(ctx, [(p, "chr5")], device_inflate=mode, block_bytes=1 << 20)
     q = str(tmp_path / "mal.vcf")
-    open(q, "wb").write(text[:4000] + b"chr5\tnotanumber\t.\tA\tC\t.\t.\t.\tGT" + b"\t0|1" * S + b"\n")
+    open(q, "wb").write(text[:text.rfind(b"\n", 0, 4000) + 1] + b"chr5\tnotanumber\t.\tA\tC\t.\t.\t.\tGT" + b"\t0|1" * S + b"\n")
     with pytest.raises(dev.HhgtError, match="Error parsing VCF file"):
         run_engine(ctx, [(q, "")])
     with pytest.raises(dev.HhgtError, match="cannot open"):
