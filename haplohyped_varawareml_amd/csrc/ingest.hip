@@ -107,7 +107,7 @@ struct Input {
     uint64_t mem_bytes = 0;
     // discovered by the source thread
     std::string header;
-    uint64_t S = 0;
+    uint64_t S = 0, S_file = 0, header_lines = 0;
     bool dev_inflate = false, is_bgzf = false;
     hhgt_reader *rd = nullptr;   // opened (possibly ahead of time) by the source thread
     // written by the driver / shipper
@@ -172,8 +172,8 @@ struct OutSlot {
 #define N_TEXT_DEV 4
 #define N_RES 4
 #define N_VAR 6
-#define N_DST 3
-#define N_OUT 4
+#define N_DST 4
+#define N_OUT 5
 
 }  // namespace
 
@@ -381,6 +381,9 @@ bool set_header(hhgt_ingest *g, Input *in, const uint8_t *p, size_t n, bool at_e
         return false;
     }
     in->header.assign(reinterpret_cast<const char *>(p), hb);
+    in->header_lines = 0;
+    for (size_t i = 0; i < hb; ++i) in->header_lines += p[i] == '\n';
+    in->S_file = S;
     in->S = g->o.sites_only ? 0 : S;
     in->st.n_samples = in->S;
     return true;
@@ -519,7 +522,7 @@ __global__ void k_count_bad_members(const uint32_t *__restrict__ st, uint64_t n,
 // wants >= 10 k members to fill the chip).
 bool run_device_inflate_input(hhgt_ingest *g, Input *in)
 {
-    const uint64_t bb = g->o.block_bytes ? g->o.block_bytes : (1ull << 30);
+    const uint64_t bb = g->o.block_bytes ? g->o.block_bytes : (512ull << 20);
     int fd = open(in->path.c_str(), O_RDONLY);
     struct stat st;
     if (fd < 0 || fstat(fd, &st) != 0) {
@@ -562,7 +565,10 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
     bool first = true;
     int sidx = 0;
     double ratio = 24.0;        // text bytes per file byte, refined as blocks go by
-    uint64_t budget = bb < (96ull << 20) ? bb : (96ull << 20);   // text budget of the first block
+    // text budget of the first block: small when nothing is in flight (the GPU starts after ~1 ms of host work instead
+    // of ~5), full size when earlier inputs still keep the device busy (a small launch fills a fraction of the chip)
+    const bool idle = g->free_text.size() == g->text.size() && g->q_text.size() == 0;
+    uint64_t budget = idle ? (bb < (96ull << 20) ? bb : (96ull << 20)) : bb;
     uint64_t member_index = 0;
     if (flen == 0) {
         fail(g, HHGT_ERR_MALFORMED, "empty file (no VCF header)");
@@ -831,7 +837,7 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     const uint64_t S = in->S;
     const int32_t sc = g->o.sc, vc = g->o.vc;
     // a kept line holds S sample columns of at least two bytes behind nine fixed columns
-    X->kept_per_block = block_bytes / (2 * S + 16) + 2;
+    X->kept_per_block = block_bytes / (2 * in->S_file + 16) + 2;
     const uint64_t W = X->kept_per_block / (uint64_t)vc + 2;   // chunk columns one block can touch
     X->ring_cols = 2 * W + 6;
     memset(&X->lay, 0, sizeof(X->lay));
@@ -849,8 +855,10 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     G_TRY(X->t_ref.ensure((size_t)X->lay.v_capacity));
     G_TRY(X->t_alt.ensure((size_t)X->lay.v_capacity));
     G_TRY(X->cursor.ensure(8));
-    // sample padding rows (S .. round_up(S, sc)) are never written by the encoder: zero once per input
-    if (gbytes) G_HIP(hipMemsetAsync(X->G.p, 0, (size_t)gbytes, g->s_main));
+    // sample padding rows (S .. round_up(S, sc)) are never written by the encoder: zeroed once per input for every
+    // ring column (everything else of a column is overwritten, or zeroed by the tail padding, before it is framed)
+    if (gbytes && S % (uint64_t)sc)
+        G_TRY(hhgt_pad_tail(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->G.p, g->s_main));
     G_HIP(hipMemsetAsync(X->cursor.p, 0, 8, g->s_main));
     X->done_cols = 0;
     X->host_cursor = 0;
@@ -972,6 +980,12 @@ bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
         fail(g, HHGT_ERR_IO, hhgt_last_error());
         return false;
     }
+    if (rec.n_lines_over && !rec.err_density) {
+        hhgt_set_error("Error parsing VCF file: %llu more lines than records of %llu samples fit in the block (blank or cut-off lines)",
+                       (unsigned long long)rec.n_lines_over, (unsigned long long)in->S_file);
+        fail(g, HHGT_ERR_MALFORMED, hhgt_last_error());
+        return false;
+    }
     G_TRY(hhgt_encode_result_status(&rec));
     if (rec.stats.n_chrom_runs > HHGT_RESULT_RUNS) {
         fail(g, HHGT_ERR_CAPACITY, "more than 16 CHROM runs in one text block: the input is not sorted by contig");
@@ -1066,10 +1080,14 @@ void driver_main(hhgt_ingest *g)
             const double tl0 = now_s();
             trace("drv:encode_launch", ti, (long long)tb.nbytes);
             G_HIP(hipStreamWaitEvent(g->s_main, tb.ready, 0));
-            // a line count cannot exceed 1024 per 16 KiB region without tripping the density check, so this bound
-            // always holds and the asynchronous encode never has to be repeated
+            // Bound on the block's line count (sizes the workspaces and every grid behind the index): a record of a
+            // file with S sample columns has at least 2 S + 17 bytes, so apart from the header lines of the first
+            // block more lines than that can only be blank or cut-off lines — which are a parse error anyway
+            // (reported as such by harvest).  The unconditional bound, 1024 lines per 16 KiB region, would size the
+            // grids for lines of 16 bytes: 10 M empty workgroups per 1 GiB block.
             const uint64_t n_regions = (tb.nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION;
-            const uint64_t max_lines = n_regions * INDEX_CAP;
+            uint64_t max_lines = tb.nbytes / (2 * in->S_file + 17) + (tb.first ? in->header_lines : 0) + 64;
+            if (max_lines > n_regions * INDEX_CAP) max_lines = n_regions * INDEX_CAP;
             G_TRY(hhgt_encode_text_async(g->ctx, tb.d, tb.nbytes, in->region.c_str(), &X->lay, X->cursor.as<uint64_t>(),
                                          (uint32_t)(max_lines > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : max_lines), X->G.p,
                                          X->t_start.as<uint32_t>(), nullptr, X->t_ref.as<uint8_t>(), X->t_alt.as<uint8_t>(), r.rec,
@@ -1207,12 +1225,17 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
     };
     hip(hipSetDevice(g->device), "hipSetDevice");
     hip(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking), "stream");
-    hip(hipStreamCreateWithFlags(&g->s_copy, hipStreamNonBlocking), "stream");
+    // the copy streams get the highest priority: on this platform pinned copies can run as blit kernels, and a blit
+    // queued behind thousands of resident LZ4 / inflate waves crawled at 4-13 GB/s (a 50 MB batch took up to 12 ms,
+    // the driver ran out of batch slots and the GPU idled)
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hip(hipStreamCreateWithPriority(&g->s_copy, hipStreamNonBlocking, prio_hi), "stream");
     hip(hipStreamCreateWithFlags(&g->s_inf, hipStreamNonBlocking), "stream");
-    hip(hipStreamCreateWithFlags(&g->s_out, hipStreamNonBlocking), "stream");
+    hip(hipStreamCreateWithPriority(&g->s_out, hipStreamNonBlocking, prio_hi), "stream");
     const bool dev = g->o.device_inflate != 0;
     const uint64_t bb_host = g->o.block_bytes ? g->o.block_bytes : (64ull << 20);
-    const uint64_t bb_dev = g->o.block_bytes ? g->o.block_bytes : (1ull << 30);
+    const uint64_t bb_dev = g->o.block_bytes ? g->o.block_bytes : (512ull << 20);
     const uint64_t bb = dev ? (bb_dev > bb_host ? bb_dev : bb_host) : bb_host;
     g->text.resize(dev ? N_TEXT_DEV : N_TEXT_HOST);
     for (size_t i = 0; i < g->text.size() && rc == HHGT_OK; ++i) {

@@ -40,7 +40,7 @@ typedef struct {
     int32_t sites_only;     /* 1: ignore sample columns (load_vcf_without_sample, cpp/parse_vcf.cpp:80-113)         */
     int32_t device_inflate; /* 1: BGZF files are inflated on the device; everything else takes the host reader     */
     int32_t n_threads;      /* host inflate threads per open file (0 = the reader's default)                       */
-    uint64_t block_bytes;   /* text block size; 0 = 64 MiB (host reader / memory) or 1 GiB (device inflate)         */
+    uint64_t block_bytes;   /* text block size; 0 = 64 MiB (host reader / memory) or 512 MiB (device inflate)         */
     int32_t files_ahead;    /* inputs opened ahead of the one being uploaded (host reader), 0 = 1                   */
     int32_t reserved;
 } hhgt_ingest_opts;
