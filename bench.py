@@ -4,31 +4,36 @@
 One "step" = one pass of the hot path over the whole workload: for each of the 22 per-chromosome
 shards (3 000 000 variants x 2504 samples, BASELINE.json configs[2] — the configuration the metric
 is quoted on; ~30 GB of text, fits one MI355X):
-    hhgt_encode_text  (line index -> fixed columns/filter -> GT tiles)  ->  int8 G, chunk-tiled
-    hhgt_pad_tail
+    hhgt_encode_text_async (line index -> fixed columns/filter -> GT tiles)  ->  int8 G, chunk-tiled
+    hhgt_pad_tail_cursor
     hhgt_compress_chunks (byte-shuffle + LZ4 -> Blosc2-framed chunks)
-Inputs (raw VCF text) are generated ON the GPU (csrc/synth.hip) before the timed region.
+Inputs (raw VCF text) are generated ON the GPU (csrc/synth.hip) before the timed region; nothing in the
+step waits on the host.  `value` is this kernel-only leg.  Outside the timed region and
+outside `value`, rank 0 at N = 1 also reports
+    correctness  every shard's chunks decoded on the GPU and compared with G, sampled variants against the
+                 generator's rule, two chunks decoded by the CPU oracle — a mismatch fails the run (rc 1)
+    host_fed     §8d (ii): the same text in pinned host memory through the ingest engine (PCIe-inclusive)
+    e2e          §8d (iii): BGZF level-6 shard files -> framed chunks on the host, host inflater (the north star's
+                 design) and device inflater
+    cpu_baseline the oracle on the host cores: matrix-shaped on 1 core and on all granted cores, and
+                 reference-shaped (one rescan of the text per sample)
 
 Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
-time); shards are independent, there is no data-path collective.  Default "weak": every rank encodes
-its own 3 M-variant cohort (different seeds).  --scaling strong splits the 22 shards of ONE cohort
-over the ranks (longest-processing-time-first), as the north star's per-chromosome sharding does.
+time); shards are independent, there is no data-path collective.  `--gpus N` without a launcher starts the
+N ranks itself (before this process touches a GPU); under torchrun the given environment is used.  Default
+"weak": every rank encodes its own 3 M-variant cohort (different seeds).  --scaling strong splits the 22
+shards of ONE cohort over the ranks (longest-processing-time-first), as the north star's per-chromosome
+sharding does.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from haplohyped_varawareml_amd import device as dev  # noqa: E402
-from haplohyped_varawareml_amd import synth  # noqa: E402
-from haplohyped_varawareml_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
@@ -41,16 +46,42 @@ def parse_args():
     ap.add_argument("--variants", type=int, default=3_000_000)
     ap.add_argument("--samples", type=int, default=2504)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--vc", type=int, default=dev.DEFAULT_VC, help="variants per chunk (chunk = 64 x vc x 2 bytes)")
-    ap.add_argument("--blocksize", type=int, default=dev.DEFAULT_BLOCKSIZE, help="Blosc2 block bytes")
+    ap.add_argument("--vc", type=int, default=8192, help="variants per chunk (chunk = 64 x vc x 2 bytes)")
+    ap.add_argument("--blocksize", type=int, default=8192, help="Blosc2 block bytes")
     ap.add_argument("--clevel", type=int, default=5, help="codec level (reference: 5); 1-2 = run-only fast mode")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encode/compress overlap")
     ap.add_argument("--lookahead", type=int, default=1, help="shards the encode stream runs ahead of the compress stream")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one GPU in rehearsals")
+    ap.add_argument("--dist-backend", default="", help="nccl (= RCCL; default) or gloo (ranks sharing one GPU in rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
-    ap.add_argument("--cpu-extended", action="store_true", help="also time the all-cores and the reference-shaped CPU baselines")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU work of each baseline shape")
+    ap.add_argument("--no-legs", action="store_true", help="skip the host-fed / end-to-end legs")
+    ap.add_argument("--legs-chroms", default="1,2,3,4", help="shards the host-fed / end-to-end legs run on")
+    ap.add_argument("--no-check", action="store_true", help="skip the correctness gate")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-GPU launch without an outside launcher
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N and no WORLD_SIZE: start the N ranks here.  This process has not touched a GPU (it imports nothing
+    that initialises HIP), so the children are ordinary child processes, not re-executions of a GPU process."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 class Shard:
@@ -58,6 +89,8 @@ class Shard:
 
 
 def build_shards(ctx, args, rank, world):
+    import torch
+    from haplohyped_varawareml_amd import device as dev, sharding, synth
     sizes = synth.shard_sizes(args.variants)
     mine, seed_off = sharding.plan(sizes, rank, world, args.scaling)
     S = args.samples
@@ -71,7 +104,7 @@ def build_shards(ctx, args, rank, world):
         tab = synth.variant_table(seed, V, S)
         text, nbytes = ctx.synth_fixed(contig, tab, S, seed=seed)
         sh = Shard()
-        sh.contig, sh.V, sh.text, sh.nbytes = contig, V, text, nbytes
+        sh.contig, sh.V, sh.text, sh.nbytes, sh.seed, sh.tab, sh.chrom = contig, V, text, nbytes, seed, tab, ci + 1
         sh.layout = dev.make_layout(S, V, vc=args.vc)
         cap = sh.layout.v_capacity
         d = ctx.device
@@ -84,7 +117,6 @@ def build_shards(ctx, args, rank, world):
         sh.n_chunks = sh.res.G.numel() // sh.chunk_nbytes
         sh.dst = torch.empty(sh.n_chunks * (sh.chunk_nbytes + 32), dtype=torch.uint8, device=d)
         sh.off = torch.zeros(sh.n_chunks + 1, dtype=torch.int64, device=d)
-        sh.total = 0
         sh.cmp_done = None
         sh.cursor = torch.zeros(1, dtype=torch.int64, device=d)
         sh.pending = dev.PendingEncode()
@@ -94,21 +126,26 @@ def build_shards(ctx, args, rank, world):
 
 
 def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
-    """encode + pad + compress of every shard.  With two streams the (issue-bound) LZ4 kernel of shard k
-    overlaps the (HBM-bound) index/encode kernels of shard k+1 — the same software pipeline the streaming
-    converter uses; every kernel still runs once per shard per step."""
+    """encode + pad + compress of every shard, queued without any host wait (asynchronous chain: the append position
+    and every count stay on the device).  With two streams the (issue-bound) LZ4 kernel of shard k overlaps the
+    (HBM-bound) index/encode kernels of shard k+1 — the same software pipeline the ingest engine uses; every kernel
+    still runs once per shard per step."""
+    import torch
+    from haplohyped_varawareml_amd import device as dev
+
     def encode(sh):
-        # asynchronous chain: the append position and every count stay on the device (hhgt_encode_text_async), so
-        # the host never waits inside a step and the encode stream runs ahead of the compress stream by itself
         sh.cursor.zero_()
         ctx.encode_text_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
         ctx.pad_tail_cursor(sh.res, sh.cursor)
 
+    def compress(sh):
+        ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2, dst=sh.dst,
+                     chunk_off=sh.off, sync=False)
+
     if streams is None:
         for sh in shards:
             encode(sh)
-            ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2,
-                         dst=sh.dst, chunk_off=sh.off, sync=False)
+            compress(sh)
         return
     s_enc, s_cmp = streams
 
@@ -122,12 +159,9 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
     def cmp_(sh):
         with torch.cuda.stream(s_cmp):
             s_cmp.wait_event(sh.ready)
-            ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2,
-                         dst=sh.dst, chunk_off=sh.off, sync=False)
+            compress(sh)
             sh.cmp_done = s_cmp.record_event()
 
-    # nothing blocks the host: the whole step is queued at once; `lookahead` only bounds how far the encode stream may
-    # run ahead of the compress stream (G of shard k is rewritten by the next step's encode)
     n = len(shards)
     for i in range(min(lookahead, n)):
         enc(shards[i])
@@ -137,99 +171,236 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
             enc(shards[k + lookahead])
 
 
-def cpu_baseline(ctx, shards, S, target_s, extended=False):
-    """oracle (CPU restatement of the reference path, matrix-shaped, 1 thread) on a bounded sample of
-    the same workload: the first n lines of the largest shard."""
+# ---------------------------------------------------------------------------------------------------------------
+# correctness gate (outside the timed region)
+# ---------------------------------------------------------------------------------------------------------------
+def correctness_gate(ctx, shards, S, blocksize):
+    """What the timed steps left in HBM is checked three ways; any mismatch raises (the run exits non-zero).
+    (1) every shard: its framed chunks are decoded by the GPU decoder and compared with G byte for byte;
+    (2) every shard: 64 sampled variants of G against the generator's rule (synth.genotype_bits) — the encode side;
+    (3) two chunks (first shard's first, last shard's last) are decoded by the CPU oracle."""
+    import numpy as np
+    import torch
+    from haplohyped_varawareml_amd import synth
+    from oracle import oracle
+    rep = dict(shards=len(shards), chunks_decoded_gpu=0, variants_sampled=0, chunks_decoded_oracle=0)
+    rng = np.random.default_rng(12345)
+    for sh in shards:
+        rec = sh.pending.wait()                      # raises on malformed text / capacity
+        if rec.cursor_after != sh.V or rec.stats.n_kept != sh.V:
+            raise AssertionError(f"{sh.contig}: kept {rec.stats.n_kept} of {sh.V} records")
+        back, bad = ctx.decompress(sh.dst, sh.off, sh.n_chunks, sh.chunk_nbytes, typesize=2, blocksize=blocksize)
+        if bad or not torch.equal(back, sh.res.G):
+            raise AssertionError(f"{sh.contig}: decoded chunks differ from the genotype matrix ({bad} chunks flagged)")
+        rep["chunks_decoded_gpu"] += sh.n_chunks
+        del back
+        vs = np.unique(np.concatenate([[0, sh.V - 1], rng.integers(0, sh.V, 62)]))
+        lay = sh.layout
+        g = sh.res.G.view(torch.int8).view(lay.v_capacity // lay.vc, -(-S // lay.sc), lay.sc, lay.vc, 2)
+        for v in vs:
+            want = synth.genotype_bits(sh.seed, int(v), 1, S, sh.tab["thr"][v:v + 1])[0]          # [S, 2]
+            got = g[int(v) // lay.vc, :, :, int(v) % lay.vc, :].reshape(-1, 2)[:S].cpu().numpy()
+            if not np.array_equal(got, want.astype(np.int8)):
+                raise AssertionError(f"{sh.contig}: variant {v} differs from the generator's genotypes")
+        rep["variants_sampled"] += len(vs)
+    for sh, k in ((shards[0], 0), (shards[-1], shards[-1].n_chunks - 1)):
+        off = sh.off[k:k + 2].cpu().numpy()
+        chunk = sh.dst[int(off[0]):int(off[1])].cpu().numpy()
+        raw = sh.res.G[k * sh.chunk_nbytes:(k + 1) * sh.chunk_nbytes].cpu().numpy()
+        if not np.array_equal(oracle.blosc_decompress(chunk), raw):
+            raise AssertionError(f"{sh.contig}: chunk {k} does not decode (oracle) to the matrix bytes")
+        rep["chunks_decoded_oracle"] += 1
+    rep["ok"] = True
+    return rep
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1): the oracle on the host cores
+# ---------------------------------------------------------------------------------------------------------------
+def effective_cpus():
+    import ctypes
+    from haplohyped_varawareml_amd import _lib
+    L = _lib.load()
+    L.hhgt_effective_cpus.restype = ctypes.c_int
+    return int(L.hhgt_effective_cpus())
+
+
+def cpu_baseline(shards, S, target_s):
+    """SURVEY.md §8d's three shapes, each bounded to about target_s seconds of CPU work on a sample of the same
+    workload (the first n lines of the largest shard):
+      value / port      matrix-shaped, 1 core: one pass over the text encodes every sample, then shuffle + LZ4 + framing
+      all_cores         the same on every CPU the process is granted (line-aligned pieces, one thread each: the
+                        oracle is plain C behind ctypes, the GIL is released)
+      reference_shaped  one call per sample that rescans the whole text, as /root/reference/cpp/parse_vcf.cpp:30-71 is
+                        driven by vcf_to_h5.py:96-101 — timed for a few samples, scaled to S calls"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     sh = max(shards, key=lambda s: s.V)
     bytes_per_line = sh.nbytes / max(sh.V, 1)
 
-    def run(n_lines):
+    def sample(n_lines):
         nb = min(sh.nbytes, int(n_lines * bytes_per_line) + 65536)
         host = sh.text[:nb].cpu().numpy()
-        last_nl = int(np.flatnonzero(host == 10)[-1]) + 1
-        host = host[:last_nl]
-        t0 = time.perf_counter()
-        o = oracle.vcf_encode(host, S, region=sh.contig, cap=n_lines + 64)
-        t1 = time.perf_counter()
-        G = o["G"]                       # [S, V, 2]; one sample row per Blosc block, 64 rows per chunk
-        V = G.shape[1]
-        cbytes = 0
-        blk = V * 2
-        for s0 in range(0, S, 64):
-            raw = np.ascontiguousarray(G[s0:s0 + 64]).reshape(-1).view(np.uint8)
-            cbytes += oracle.blosc_compress(raw, 2, min(blk, 65536 - (65536 % 2))).size
-        t2 = time.perf_counter()
-        return V, t1 - t0, t2 - t1, cbytes, G.size
-
-    V0, te, tc, _, _ = run(4000)
-    per_line = (te + tc) / max(V0, 1)
-    n = int(min(sh.V, max(4000, target_s / max(per_line, 1e-9))))
-    V, te, tc, cb, raw = run(n)
-    out = {
-        "value": V / (te + tc), "unit": "variants/s", "cores": 1, "kind": "port",
-        "sample": f"first {V} variants of {sh.contig} ({S} samples): oracle encode {te:.2f}s + shuffle/LZ4/Blosc2 {tc:.2f}s, ratio {raw / max(cb, 1):.2f}",
-    }
-    if extended:
-        out.update(cpu_baseline_extended(oracle, sh, S, bytes_per_line, n))
-    return out
-
-
-def cpu_baseline_extended(oracle, sh, S, bytes_per_line, n_lines):
-    """SURVEY.md §8d's other two baseline shapes (--cpu-extended; not part of the default run):
-    matrix-shaped on all host cores (the oracle is plain C behind ctypes: threads run it in parallel) and
-    reference-shaped — one call per sample that rescans the whole text, as /root/reference/cpp/parse_vcf.cpp:30-71
-    is driven by vcf_to_h5.py:96-101 — timed for a few samples and scaled to S calls."""
-    from concurrent.futures import ThreadPoolExecutor
-    nb = min(sh.nbytes, int(n_lines * bytes_per_line) + 65536)
-    host = sh.text[:nb].cpu().numpy()
-    host = host[:int(np.flatnonzero(host == 10)[-1]) + 1]
-    T = min(os.cpu_count() or 1, 64)
-    nl = np.flatnonzero(host == 10)
-    cuts = [0] + [int(nl[min(len(nl) - 1, (len(nl) * (i + 1)) // T - 1)]) + 1 for i in range(T)]
-    pieces = [host[cuts[i]:cuts[i + 1]] for i in range(T) if cuts[i + 1] > cuts[i]]
+        return host[:int(np.flatnonzero(host == 10)[-1]) + 1]
 
     def work(piece):
         o = oracle.vcf_encode(piece, S, region=sh.contig)
         G = o["G"]
+        V = G.shape[1]
+        cb = 0
         for s0 in range(0, S, 64):
             raw = np.ascontiguousarray(G[s0:s0 + 64]).reshape(-1).view(np.uint8)
-            oracle.blosc_compress(raw, 2, min(G.shape[1] * 2, 65536))
-        return G.shape[1]
+            cb += oracle.blosc_compress(raw, 2, min(V * 2, 65536 - (65536 % 2))).size
+        return V, cb, G.size
 
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(T) as ex:
-        Vall = sum(ex.map(work, pieces))
+    V0, _, _ = work(sample(2000))
+    per_line = (time.perf_counter() - t0) / max(V0, 1)
+    n1 = int(min(sh.V, max(2000, target_s / max(per_line, 1e-9))))
+    host = sample(n1)
+    t0 = time.perf_counter()
+    V1, cb, raw = work(host)
+    t_one = time.perf_counter() - t0
+    cores = effective_cpus()
+    out = {"value": V1 / t_one, "unit": "variants/s", "cores": 1, "kind": "port",
+           "sample": f"first {V1} variants of {sh.contig} ({S} samples): oracle encode + shuffle/LZ4/Blosc2 on one core in "
+                     f"{t_one:.2f}s, ratio {raw / max(cb, 1):.2f}"}
+    # all cores: cores x the single-core sample, cut at line ends
+    host = sample(min(sh.V, n1 * cores))
+    nl = np.flatnonzero(host == 10)
+    cuts = [0] + [int(nl[min(len(nl) - 1, (len(nl) * (i + 1)) // cores - 1)]) + 1 for i in range(cores)]
+    pieces = [host[cuts[i]:cuts[i + 1]] for i in range(cores) if cuts[i + 1] > cuts[i]]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        Vall = sum(r[0] for r in ex.map(work, pieces))
     t_all = time.perf_counter() - t0
-    # reference-shaped: 3 single-sample calls over a 20 k-line slice
-    k = min(len(nl), 20000)
+    out["all_cores"] = {"value": Vall / t_all, "unit": "variants/s", "cores": cores, "kind": "port",
+                        "sample": f"{Vall} variants in {len(pieces)} line-aligned pieces, one thread each, {t_all:.2f}s"}
+    # reference-shaped: single-sample calls over a slice sized for ~target_s / 3 per call
+    k = int(min(len(nl), max(2000, n1 // 2)))
     sl = host[:int(nl[k - 1]) + 1]
     t0 = time.perf_counter()
     for si in (0, S // 2, S - 1):
         oracle.vcf_load_sample(sl, S, si, region=sh.contig)
     t_call = (time.perf_counter() - t0) / 3
-    return {
-        "all_cores": {"value": Vall / t_all, "unit": "variants/s", "cores": T, "sample": f"{Vall} variants in {len(pieces)} line-aligned pieces"},
-        "reference_shaped": {"value": k / (t_call * S), "unit": "variants/s", "cores": 1,
-                             "sample": f"one rescan per sample ({t_call * 1e3:.1f} ms per call over {k} lines) x {S} samples, parse only"},
-    }
+    out["reference_shaped"] = {"value": k / (t_call * S), "unit": "variants/s", "cores": 1, "kind": "port",
+                               "sample": f"one rescan of the text per sample ({t_call * 1e3:.0f} ms per call over {k} lines) x {S} "
+                                         f"samples, parse only (no re-pack, no codec)"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host-fed and end-to-end legs (rank 0, N = 1): the ingest engine on a bounded set of shards
+# ---------------------------------------------------------------------------------------------------------------
+def ingest_legs(ctx, shards, S, chroms, fmt):
+    import shutil
+    import tempfile
+    import torch
+    from haplohyped_varawareml_amd.ingest import Columns, Ingest, InputEnd
+    from haplohyped_varawareml_amd.reader import write_bgzf_native
+    pick = [sh for sh in shards if sh.chrom in chroms]
+    if not pick:
+        return None, None
+    V = sum(sh.V for sh in pick)
+    text_bytes = sum(sh.nbytes for sh in pick)
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.perf_counter()
+        hosts, files = [], []
+        for sh in pick:
+            h = torch.empty(sh.nbytes, dtype=torch.uint8).pin_memory()
+            h.copy_(sh.text)
+            hosts.append(h)
+            p = os.path.join(d, f"{sh.contig}.filtered.vcf.gz")
+            write_bgzf_native(p, h.numpy(), level=6)
+            files.append(p)
+        prep = time.perf_counter() - t0
+        file_bytes = sum(os.path.getsize(p) for p in files)
+
+        def h2d_rate():
+            dd = torch.empty(hosts[0].numel(), dtype=torch.uint8, device=ctx.device)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                dd.copy_(hosts[0], non_blocking=True)
+            torch.cuda.synchronize()
+            return 3 * hosts[0].numel() / (time.perf_counter() - t) / 1e9
+
+        link = h2d_rate()
+
+        def run(jobs, device_inflate, passes=3):
+            with Ingest(ctx, fmt=fmt, device_inflate=device_inflate) as ing:
+                best = None
+                first = None
+                for _ in range(passes):
+                    t = time.perf_counter()
+                    for src, sh in jobs:
+                        ing.add_file(src, sh.contig) if isinstance(src, str) else ing.add_memory(src, sh.contig)
+                    framed = kept = n_end = 0
+                    for ev in ing.events():
+                        if isinstance(ev, Columns):
+                            framed += ev.framed.size
+                        elif isinstance(ev, InputEnd):
+                            kept += ev.stats["n_kept"]
+                            n_end += 1
+                            if n_end == len(jobs):
+                                break
+                    dt = time.perf_counter() - t
+                    if kept != V:
+                        raise AssertionError(f"ingest leg kept {kept} of {V} records")
+                    first = first if first is not None else dt
+                    best = dt if best is None or dt < best else best
+            return best, first, framed
+
+        what = f"chr{','.join(str(sh.chrom) for sh in pick)} of the cohort: {V} variants x {S} samples, {text_bytes / 1e9:.2f} GB of text"
+        tb, tf, framed = run([(h, sh) for h, sh in zip(hosts, pick)], False)
+        host_fed = {"value": V / tb, "unit": "variants/s", "text_GBps": text_bytes / tb / 1e9, "pinned_h2d_GBps": link,
+                    "frac_of_h2d": text_bytes / tb / 1e9 / link, "seconds": tb, "first_pass_seconds": tf,
+                    "sample": what + ", in pinned host memory -> 64 MiB blocks -> hipMemcpyAsync -> encode + compress -> framed chunks "
+                                     "copied back to pinned memory (ingest engine warm: best of 3 passes)",
+                    "ratio": V * S * 2 / max(framed, 1)}
+        e2e = {"sample": what + f", as {len(files)} BGZF level-6 files in /dev/shm ({file_bytes / 1e6:.0f} MB) -> framed chunks in "
+                                f"pinned host memory (ingest engine warm: best of 3 passes; first pass = with the engine's pinned staging "
+                                f"still to be allocated)", "file_bytes": file_bytes, "prep_seconds": prep,
+               "host_cpus": effective_cpus()}
+        for name, devinf in (("host_inflate", False), ("device_inflate", True)):
+            tb, tf, framed = run([(p, sh) for p, sh in zip(files, pick)], devinf)
+            e2e[name] = {"value": V / tb, "unit": "variants/s", "text_GBps": text_bytes / tb / 1e9, "seconds": tb,
+                         "first_pass_seconds": tf, "file_GBps": file_bytes / tb / 1e9,
+                         "inflater": "hhgt_reader: zlib inflate + PCLMUL CRC-32 on the granted host CPUs -> pinned ring -> hipMemcpyAsync"
+                         if not devinf else "k_inflate_members + k_crc32_members on the device (compressed members cross PCIe)"}
+        return host_fed, e2e
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np  # noqa: F401
+    import torch
+    from haplohyped_varawareml_amd import device as dev
+    from haplohyped_varawareml_amd import sharding
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1
+    n_dev = max(torch.cuda.device_count(), 1)
+    shared_gpu = world > n_dev            # rehearsal: more ranks than GPUs (RCCL cannot put two ranks on one device)
+    backend = args.dist_backend or ("gloo" if shared_gpu else "nccl")
+    local_rank = local_rank % n_dev
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     ctx = dev.Context(local_rank)
     ctx.set_clevel(args.clevel)
@@ -267,13 +438,20 @@ def main():
     stages = ctx.profile_read()
     ctx.profile(False)
 
-    dt_max, total_variants = sharding.reduce_job(dist if use_dist else None, dt, my_variants, device="cuda")
+    dev_for_reduce = "cuda" if backend == "nccl" else "cpu"
+    dt_max, total_variants = sharding.reduce_job(dist if use_dist else None, dt, my_variants, device=dev_for_reduce)
+
+    failed = None
+    check = None
+    if not args.no_check:
+        try:
+            check = correctness_gate(ctx, shards, S, args.blocksize)
+        except Exception as e:      # reported in the line, and the run exits non-zero
+            failed = f"{type(e).__name__}: {e}"
+            check = {"ok": False, "error": failed}
 
     # sizes for the roofline (algorithmic bytes), this rank
     comp_bytes = sum(int(sh.off[-1].item()) for sh in shards)
-    for sh in shards:
-        rec = sh.pending.wait()                                             # raises on malformed text / capacity
-        assert rec.cursor_after == sh.V, (sh.contig, rec.cursor_after, sh.V)
     g_bytes = sum(sh.V * 2 * S for sh in shards)                             # V' * 2S (every synthetic record is kept)
     alg = {
         "index": text_bytes, "fixed": 0, "encode": sum(sh.V * 4 * S for sh in shards) + g_bytes,
@@ -284,9 +462,10 @@ def main():
     dom_ms_per_launch = stages[dom]["ms"] / max(stages[dom]["launches"], 1)
     dom_bytes_per_launch = alg[dom] / max(len(shards), 1)                     # one launch per shard per step
     achieved = dom_bytes_per_launch / (dom_ms_per_launch * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected
-    # in separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch size
-    traffic = None
+    # HBM traffic of the dominant kernel: NOT measured in this run — per-variant bytes of the newest committed PMC
+    # passes (FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 runs on a 300 k-variant workload and corrected
+    # as MI355X_MICROARCH.md prescribes), scaled to this launch size
+    traffic, traffic_source = None, None
     import glob
     pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))   # newest build last (r01, r01b, r02 ...)
     if pmcs:
@@ -294,13 +473,21 @@ def main():
             per_variant = json.load(open(pmcs[-1])).get(dom, {}).get("hbm_bytes_per_variant")
             if per_variant and S == 2504:
                 traffic = per_variant * my_variants / max(len(shards), 1)
+                traffic_source = (f"{os.path.basename(pmcs[-1])}: {per_variant:.0f} B/variant from separate --pmc passes "
+                                  f"(300 k variants), scaled to this launch; not collected in this run")
         except Exception:
             traffic = None
+    # whole path against SURVEY.md §8d's definition: B = B_enc + B_cmp (unfused: V (F + 6 S) + V' 2 S (1 + 1/r)) per
+    # step, over the step time, over the HBM peak
+    b_whole = text_bytes + g_bytes + g_bytes + comp_bytes
+    step_s = dt_max / args.steps
     roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_blocks", "encode": "k_encode_tiles", "index": "k_index_newlines",
                                        "frame": "k_frame_write"}.get(dom, dom),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "bytes_per_launch": dom_bytes_per_launch, "ms_per_launch": dom_ms_per_launch}
+            "traffic": traffic, "traffic_source": traffic_source,
+            "bytes_per_launch": dom_bytes_per_launch, "ms_per_launch": dom_ms_per_launch,
+            "whole_path": {"bytes_per_step": b_whole, "GBps": b_whole / step_s / 1e9, "frac": b_whole / step_s / 1e9 / HBM_PEAK_GBS,
+                           "definition": "SURVEY 8d: V (F + 6 S) + V' 2 S (1 + 1/r) over the step time over 8 TB/s"}}
     if dom == "lz4":
         # the contract's roofline is HBM or MFMA; this kernel is bound by neither
         roof["limiter"] = "instruction issue: VALU and scalar unit ~90 % busy per PMC (profiles/*_pmc_lz4_sq.csv), HBM idle"
@@ -316,21 +503,34 @@ def main():
                    "variants_per_gpu": my_variants, "samples": S, "text_bytes_per_gpu": text_bytes,
                    "chunk": f"64 samples x {args.vc} variants x 2 int8, Blosc2 block {args.blocksize} B, typesize 2 (byte-shuffle), LZ4 clevel {args.clevel}",
                    "compression_ratio": g_bytes / max(comp_bytes, 1),
-                   "parallelism": f"per-chromosome shards x{world}, no collective",
+                   "parallelism": f"per-chromosome shards x{world}, no collective"
+                                  + (f" ({backend}: {world} ranks on {n_dev} GPU: a rehearsal, not a scaling measurement)" if shared_gpu else ""),
                    "streams": 1 if args.no_overlap else 2},
         "roofline": roof,
+        "correctness": check,
         "stages_ms_per_step": {k: v["ms"] for k, v in stages_serial.items()},
         "stages_ms_per_step_timed_region": {k: v["ms"] / args.steps for k, v in stages.items()},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ctx, shards, S, args.cpu_seconds, args.cpu_extended)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not failed:
+        if not args.no_legs:
+            try:
+                chroms = {int(x) for x in args.legs_chroms.split(",") if x}
+                out["host_fed"], out["e2e"] = ingest_legs(ctx, shards, S, chroms, dev.BLOSC2)
+            except Exception as e:
+                failed = f"ingest legs: {type(e).__name__}: {e}"
+                out["host_fed"] = out["e2e"] = {"error": failed}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(shards, S, args.cpu_seconds)
     if rank == 0:
+        out.setdefault("cpu_baseline", None)
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write(f"bench.py: FAILED: {failed}\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":
