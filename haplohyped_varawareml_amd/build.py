@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhhgt.so")
 OBJ = os.path.join(ROOT, "build", "obj")
-SOURCES = ["scan.hip", "index.hip", "encode.hip", "lz4.hip", "frame.hip", "decode.hip", "inflate.hip", "synth.hip",
+SOURCES = ["scan.hip", "index.hip", "encode.hip", "lz4.hip", "lz4bits.hip", "frame.hip", "decode.hip", "inflate.hip", "synth.hip",
            "reader.hip", "ingest.hip", "onehot.hip", "api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 

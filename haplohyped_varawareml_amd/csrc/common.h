@@ -170,6 +170,9 @@ size_t lz4_slot_bytes(int neblock);
 int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
                       int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int fast,
                       hipStream_t st);
+// lz4bits.hip: typesize 2, 8 KiB blocks; streams it cannot code get csize = 0xFFFFFFFF
+int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+                         hipStream_t st);
 // frame.hip
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src,
                  uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,

@@ -653,6 +653,13 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
+    // algo bit 8: only the streams the bit-plane encoder (lz4bits.hip) left marked (csize == 0xFFFFFFFF) are coded
+    const bool only_marked = (algo & 0x100u) != 0u;
+    if (only_marked) {
+        bool any = false;
+        for (uint32_t w = 0; w < nwaves; ++w) any = any || csize[(uint64_t)blockIdx.x * nwaves + w] == 0xFFFFFFFFu;
+        if (!any) return;
+    }
     // wave index through readfirstlane: everything derived from it (stream base, output slot) stays in SGPRs,
     // so the byte stores below use the SGPR-base + 32-bit-offset addressing form
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
@@ -701,6 +708,7 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     }
     __syncthreads();
     // ---- phase B: one wave per stream
+    if (only_marked && csize[(uint64_t)blockIdx.x * nwaves + wave] != 0xFFFFFFFFu) return;
     if (wave < nstreams) {
         const uint8_t *in = data + (size_t)wave * pstride;
         const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
@@ -728,6 +736,16 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
                       int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int fast,
                       hipStream_t st)
 {
+    // the bit-plane encoder (lz4bits.hip) takes the case the path is built for — typesize 2, 8 KiB blocks, default
+    // effort — and marks the streams it cannot code (a byte > 1, very dense planes); this kernel then only runs those.
+    // HHGT_LZ4_BITPLANES=0 keeps everything on the byte-wise encoder.
+    static const bool bp_env = !(getenv("HHGT_LZ4_BITPLANES") && atoi(getenv("HHGT_LZ4_BITPLANES")) == 0);
+    const bool bitplanes = bp_env && fast == 0 && typesize == 2 && blocksize == 8192 && chunk_nbytes % 8192 == 0 &&
+                           (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0 && slot_bytes >= 4128;
+    if (bitplanes) {
+        const int rc = launch_lz4_bitplanes(d_src, n_chunks * (chunk_nbytes / 8192), d_scratch, slot_bytes, d_csize, st);
+        if (rc != HHGT_OK) return rc;
+    }
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
     const uint32_t nwaves = split ? (uint32_t)typesize : 1u;
     const uint32_t nblocks = (uint32_t)((chunk_nbytes + blocksize - 1) / blocksize);
@@ -774,7 +792,8 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
         attr_lds = lds;
     }
     // HHGT_LZ4_ALGO: 6 = window-parallel encoder with batched emission (default), 1 = the simple first version (A/B)
-    static const uint32_t algo = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 6u;
+    static const uint32_t algo_env = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 6u;
+    const uint32_t algo = algo_env | (bitplanes ? 0x100u : 0u);
     const uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
     if (grid > 0x7fffffffull) {
@@ -797,7 +816,7 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
                        (uint64_t)slot_bytes, d_csize)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)
-    if (algo == 1u) LZ_LAUNCH(0, 1);
+    if ((algo & 0xFFu) == 1u) LZ_LAUNCH(0, 1);
     else if (fast == 1 && nwaves <= 2) LZ_LAUNCH(8, 5);
     else if (fast == 1) LZ_LAUNCH(0, 5);
     else if (fast == 2 && nwaves <= 2) LZ_LAUNCH(7, 7);

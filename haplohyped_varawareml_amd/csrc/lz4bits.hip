@@ -1,0 +1,347 @@
+// lz4bits.hip — LZ4 block encode of 0/1 byte planes by walking the ONES, not the bytes (gfx950).
+//
+// Same place in the path as lz4.hip (the shuffle + LZ4 step of the HDF5 filter the reference invokes at
+// /root/reference/src/haplohyped/vcf_to_h5.py:134-135), same output contract (a valid LZ4 block stream per Blosc
+// stream, "decompresses to identical bytes"), for the case the path is built for: typesize 2, 8 KiB Blosc blocks,
+// i.e. two 4 KiB byte planes per block, each the haplotype of one sample over 4096 variants — bytes that are 0 or 1
+// and about 94 % zeros.  The byte-wise encoder in lz4.hip spends ~3.8 k vector + ~3.3 k scalar instructions per plane
+// looking at every one of the 4096 positions (64 per window, one per lane); it is bound by instruction issue with HBM
+// at 6 %.  This kernel turns the plane into a 4096-bit map and works on the LIST OF ONES (~260 per plane):
+//
+//   * one lane per one, 64 ones per window (4-5 windows per plane instead of 52-64);
+//   * hash table keyed on the 12 bits at the one, updated by ONE ds_wrxchg_rtn_b32 per window: the LDS serves lanes
+//     that hit the same address in ascending lane order (tools/micro/lds_xchg_order.hip, checked by a test), so every
+//     lane gets the most recent earlier one with its key — exact sequential hash-table semantics, 64 insertions at once;
+//   * match lengths come from comparing GAPS between ones (a few LDS reads per one), not bytes: equal gaps, then one
+//     plus the shorter of the first unequal pair; matches are pulled back over up to 8 literal zeros in front;
+//   * every one decides locally between "match" and "literal" by cost (3 bytes per sequence against the literals and
+//     runs it replaces) and thereby where the next coded one is: the greedy parse is a linked list nxt(j), followed
+//     inside a window by pointer doubling (6 rounds), not by a serial loop;
+//   * behind whatever a coded one ends with, the zeros up to the next one go out as an offset-1 run;
+//   * every coded one lays out and writes its (at most two) sequences itself, literals generated from the bit map.
+//
+// tools/sim/gapenc_ref.c states the same algorithm on the CPU, decision for decision; the kernel's streams are
+// compared with it byte for byte (tests/test_gpu_lz4_bitplanes.py) and decoded by liblz4 / the oracle like every
+// other stream.  Planes with a byte > 1 (missing calls, -9) or more than 1020 ones are left to the byte-wise
+// encoder (csize = MARK; lz4.hip's kernel then runs in "marked streams only" mode).
+#include "common.h"
+
+#define BP_N 4096
+#define BP_MAXONES 1020
+#define BP_HLOG 8
+#define BP_MINM 6
+#define BP_BACK 8
+#define BP_STEPS 8
+#define BP_MFLIMIT (BP_N - 12)
+#define BP_MATCHLIMIT (BP_N - 5)
+
+struct BpLds {
+    uint32_t bm[132];                // bit map of the plane: 128 dwords + zero padding
+    uint32_t tab[1 << BP_HLOG];      // context hash -> one index + 1
+    uint32_t flag[68];               // pointer-doubling marks of a window
+    uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
+    uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
+};
+
+__device__ __forceinline__ uint32_t bp_scan_sum(uint32_t v, uint32_t lane)   // inclusive
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t bp_scan_max(uint32_t v, uint32_t lane)   // inclusive
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v = v > t ? v : t;
+    }
+    return v;
+}
+
+// 32 bits of the map starting at bit q (0 <= q < 4096 + 96)
+__device__ __forceinline__ uint32_t bp_bits(const volatile uint32_t *bm, uint32_t q)
+{
+    const uint32_t i = q >> 5;
+    const uint32_t lo = bm[i], hi = bm[i + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, q & 31u);
+}
+
+__device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return x >= 15u ? (x - 15u) / 255u + 1u : 0u; }
+
+// one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off)
+__device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t *__restrict__ out, uint32_t at, uint32_t anchor,
+                                           uint32_t start, uint32_t len, uint32_t off, bool on)
+{
+    const uint32_t ll = on ? start - anchor : 0u, ml = len - 4u;
+    const uint32_t llx = on ? bp_len_ext(ll) : 0u, mlx = on ? bp_len_ext(ml) : 0u;
+    if (on) {
+        out[at] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (ml < 15u ? ml : 15u));
+        uint32_t r = ll - 15u;
+        for (uint32_t k = 0; k < llx; ++k) {   // rare: >= 15 literals
+            out[at + 1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
+            r -= 255u;
+        }
+    }
+    const uint32_t lit = at + 1u + llx;
+    // literals: lockstep over the longest run of the wave; 32 bits of the map per refill
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < ll) != 0ull; k += 32u) {
+        if (k < ll) {
+            uint32_t b = bp_bits(bm, anchor + k);
+            const uint32_t cnt = ll - k < 32u ? ll - k : 32u;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                out[lit + k + t] = (uint8_t)(b & 1u);
+                b >>= 1;
+            }
+        }
+    }
+    if (on) {
+        const uint32_t o = lit + ll;
+        out[o] = (uint8_t)(off & 0xFFu);
+        out[o + 1u] = (uint8_t)(off >> 8);
+        uint32_t r = ml - 15u;
+        for (uint32_t k = 0; k < mlx; ++k) {
+            out[o + 2u + k] = (uint8_t)(k + 1u == mlx ? r : 255u);
+            r -= 255u;
+        }
+    }
+}
+
+// grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
+__global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, uint8_t *__restrict__ scratch,
+                                                          uint64_t slot_bytes, uint32_t *__restrict__ csize)
+{
+    __shared__ BpLds lds[2];
+    __shared__ uint32_t nonbin[2][2];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    const uint8_t *blk = src + (uint64_t)blockIdx.x * 8192u;
+
+    // ---- phase A: wave r packs the bits of block bytes [4096 r, 4096 r + 4096) for BOTH planes (byte-shuffle fused:
+    //      even bytes are plane 0, odd bytes plane 1); lane L handles 64 contiguous bytes = 32 positions of each plane
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(blk + 4096u * wave + 64u * lane);
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(p + k);   // streamed once
+        uint32_t acc0 = 0, acc1 = 0, nb0 = 0, nb1 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t x = d[i];
+                nb0 |= x & 0x00FE00FEu;
+                nb1 |= x & 0xFE00FE00u;
+                const uint32_t y = x | (x >> 15);   // bits 0,1: plane-0 bytes; bits 8,9: plane-1 bytes
+                acc0 |= (y & 3u) << (2 * (4 * k + i));
+                acc1 |= ((y >> 8) & 3u) << (2 * (4 * k + i));
+            }
+        }
+        lds[0].bm[64u * wave + lane] = acc0;
+        lds[1].bm[64u * wave + lane] = acc1;
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nb0 != 0u), b1 = __builtin_amdgcn_ballot_w64(nb1 != 0u);
+        if (lane == 0) {
+            nonbin[wave][0] = b0 != 0ull;
+            nonbin[wave][1] = b1 != 0ull;
+        }
+        if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
+    }
+    __syncthreads();
+
+    // ---- phase B: wave w codes plane w
+    BpLds &S = lds[wave];
+    volatile uint32_t *bm = S.bm;
+    volatile uint16_t *P = S.P;
+    volatile uint16_t *wpre = S.wpre;
+    volatile uint32_t *flag = S.flag;
+    const uint64_t sidx = (uint64_t)blockIdx.x * 2u + wave;
+    uint8_t *out = scratch + sidx * slot_bytes;
+
+    const uint32_t wlo = bm[2u * lane], whi = bm[2u * lane + 1u];
+    const uint32_t cnt = (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
+    const uint32_t incl = bp_scan_sum(cnt, lane);
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if ((nonbin[0][wave] | nonbin[1][wave]) != 0u || m > BP_MAXONES) {
+        if (lane == 0) csize[sidx] = 0xFFFFFFFFu;   // left to the byte-wise encoder
+        return;
+    }
+    wpre[lane] = (uint16_t)(incl - cnt);
+    {   // the list of ones
+        uint32_t lo = wlo, hi = whi, at = incl - cnt + 1u;
+        if (lane == 0) P[0] = 0;
+        while (__builtin_amdgcn_ballot_w64((lo | hi) != 0u) != 0ull) {
+            if ((lo | hi) != 0u) {
+                uint32_t t;
+                if (lo) {
+                    t = (uint32_t)__builtin_ctz(lo);
+                    lo &= lo - 1u;
+                } else {
+                    t = 32u + (uint32_t)__builtin_ctz(hi);
+                    hi &= hi - 1u;
+                }
+                P[at++] = (uint16_t)(64u * lane + t + 1u);
+            }
+        }
+        if (lane < 4u) P[m + 1u + lane] = (uint16_t)(BP_N + 1);
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << BP_HLOG) / 64; ++k) S.tab[64 * k + lane] = 0u;
+
+    uint32_t op = 0, prev_end = 0;
+    int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
+    for (int jw = -1; jw < (int)m; jw += 64) {
+        const int j = jw + (int)lane;
+        const bool valid = j < (int)m;
+        const uint32_t jj = valid ? (uint32_t)(j + 1) : 0u;          // index into P of this one
+        const uint32_t q1 = P[jj], qn1 = P[jj + 1u];
+        const uint32_t qp1 = jj ? P[jj - 1u] : 0u;
+        const int q = (int)q1 - 1;
+        // ---- hash table: context of 12 bits at the one; exact recency through the LDS's lane order
+        const bool can = valid && j >= 0 && q + 12 <= BP_N;
+        uint32_t jc1 = 0;
+        if (can) {
+            const uint32_t ctx = bp_bits(bm, (uint32_t)q) & 0xFFFu;
+            const uint32_t idx = (ctx * 2654435761u) >> (32 - BP_HLOG);
+            jc1 = atomicExch(&S.tab[idx], (uint32_t)(j + 1));
+        }
+        // ---- candidate: forward length from the gaps
+        const bool have = can && jc1 != 0u;
+        uint32_t len = 0, costR = 0, tailz = 0;
+        const uint32_t c1 = have ? (uint32_t)P[jc1] : 0u;   // P[jc + 1] with jc = jc1 - 1
+        {
+            uint32_t a = jj, b = jc1, pa = q1, pb = c1;
+            bool act = have;
+            for (int s = 0; s <= BP_STEPS; ++s) {
+                if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                if (act) {
+                    const uint32_t na = P[a + 1u], nbn = P[b + 1u];
+                    const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
+                    costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
+                    if (ga != gb || a >= m || s >= BP_STEPS) {   // a = j + 1: "a + 1 >= m" of the reference
+                        const uint32_t z = ga < gb ? ga : gb;
+                        len += 1u + z;
+                        tailz = ga - z;
+                        act = false;
+                    } else {
+                        len += 1u + ga;
+                        ++a;
+                        ++b;
+                        pa = na;
+                        pb = nbn;
+                    }
+                }
+            }
+        }
+        uint32_t nb = 0;
+        bool hv = false;
+        if (have) {
+            const uint32_t gq = q1 - qp1 - 1u, gc = c1 - (uint32_t)P[jc1 - 1u] - 1u;
+            nb = gq < gc ? gq : gc;
+            nb = nb < BP_BACK ? nb : BP_BACK;
+            const uint32_t costH = 3u + (len + nb >= 19u ? 1u : 0u) - nb + (tailz >= BP_MINM ? 3u : tailz);
+            uint32_t end = (uint32_t)q + len;
+            end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
+            // signed compares: costH may wrap below zero when many zeros are pulled in
+            hv = (int)costH < (int)costR && (int)end - q >= 4 && (int)end - (q - (int)nb) >= BP_MINM && q <= BP_MFLIMIT;
+            len = end - (uint32_t)q;
+        }
+        const uint32_t E = hv ? (uint32_t)q + len : (uint32_t)(q + 1);   // end of what this one codes (0 for the virtual one)
+        // first one at or behind E: ones in front of bit E of the map
+        uint32_t nxt;
+        {
+            const uint32_t w = E >> 6, bb = E & 63u;
+            if (w >= 64u) {
+                nxt = m;
+            } else {
+                const uint32_t lo = bm[2u * w], hi = bm[2u * w + 1u];
+                const uint32_t mlo = bb >= 32u ? 0xFFFFFFFFu : ((1u << bb) - 1u);
+                const uint32_t mhi = bb > 32u ? ((1u << (bb - 32u)) - 1u) : 0u;
+                nxt = (uint32_t)wpre[w] + (uint32_t)__popc(lo & mlo) + (uint32_t)__popc(hi & mhi);
+            }
+        }
+        // ---- which ones of the window are coded: follow nxt from `cur` by pointer doubling
+        bool sel = false;
+        if (cur < jw + 64) {   // (wave-uniform) otherwise the whole window lies inside an earlier match
+            const uint32_t e0 = (uint32_t)(cur - jw);
+            uint32_t jump = valid ? (nxt - (uint32_t)jw < 64u ? nxt - (uint32_t)jw : 64u) : 64u;   // nxt > j: always forward
+            const uint32_t p0 = jump;
+            flag[lane] = lane == e0 ? 1u : 0u;
+            if (lane == 0) flag[64] = 0u;
+            bool reach = lane == e0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                if (reach) flag[jump] = 1u;
+                reach = flag[lane] != 0u;
+                const uint32_t j2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jump & 63u) << 2), (int)jump);
+                jump = jump < 64u ? j2 : 64u;
+            }
+            sel = reach && valid;
+            const unsigned long long ex = __builtin_amdgcn_ballot_w64(sel && p0 == 64u);
+            // the coded one whose successor lies outside the window hands over to the next window
+            if (ex != 0ull) cur = (int)__builtin_amdgcn_readlane((int)nxt, (int)(__ffsll((long long)ex) - 1));
+        }
+        // ---- sequences of the coded ones: match M (if hv) and tail run T over the zeros up to the next one
+        const bool onM = sel && hv;
+        const uint32_t rs = E + ((E == 0u || ((bp_bits(bm, E ? E - 1u : 0u) & 1u) != 0u)) ? 1u : 0u);
+        uint32_t re = (uint32_t)P[(nxt < m ? nxt : m) + 1u] - 1u;   // position of the next one (n behind the last)
+        re = re < BP_MATCHLIMIT ? re : BP_MATCHLIMIT;
+        const bool onT = sel && (int)re - (int)rs >= BP_MINM && rs <= BP_MFLIMIT;
+        const uint32_t F = onT ? re : (onM ? E : 0u);
+        const uint32_t fincl = bp_scan_max(F, lane);
+        uint32_t pe = (uint32_t)__shfl_up(fincl, 1, 64);
+        pe = lane ? pe : 0u;
+        pe = pe > prev_end ? pe : prev_end;             // end of the previous sequence in stream order
+        uint32_t ms = (uint32_t)(q - (int)nb);
+        ms = onM ? (ms > pe ? ms : pe) : 0u;            // the previous sequence may have taken some of the zeros in front
+        const uint32_t llM = onM ? ms - pe : 0u, lenM = E - ms;
+        const uint32_t pe2 = onM ? E : pe;
+        const uint32_t llT = onT ? rs - pe2 : 0u, lenT = re - rs;
+        const uint32_t szM = onM ? 3u + bp_len_ext(llM) + llM + bp_len_ext(lenM - 4u) : 0u;
+        const uint32_t szT = onT ? 3u + bp_len_ext(llT) + llT + bp_len_ext(lenT - 4u) : 0u;
+        const uint32_t sincl = bp_scan_sum(szM + szT, lane);
+        const uint32_t at = op + sincl - (szM + szT);
+        bp_put_seq(bm, out, at, pe, ms, lenM, (uint32_t)q + 1u - c1, onM);
+        bp_put_seq(bm, out, at + szM, pe2, rs, lenT, 1u, onT);
+        op += (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        const uint32_t fmax = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
+        prev_end = fmax > prev_end ? fmax : prev_end;
+    }
+    // ---- last literals
+    {
+        const uint32_t ll = BP_N - prev_end, llx = bp_len_ext(ll);
+        if (lane == 0) {
+            out[op] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
+            uint32_t r = ll - 15u;
+            for (uint32_t k = 0; k < llx; ++k) {
+                out[op + 1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
+                r -= 255u;
+            }
+        }
+        const uint32_t lit = op + 1u + llx;
+        for (uint32_t k = lane; k < ll; k += 64u) out[lit + k] = (uint8_t)(bp_bits(bm, prev_end + k) & 1u);
+        op = lit + ll;
+    }
+    if (op >= BP_N) {   // incompressible: Blosc stores the (shuffled) stream verbatim
+        for (uint32_t k = lane; k < BP_N; k += 64u) out[k] = (uint8_t)(bp_bits(bm, k) & 1u);
+        op = BP_N;
+    }
+    if (lane == 0) csize[sidx] = op;
+}
+
+int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+                         hipStream_t st)
+{
+    if (n_blocks == 0) return HHGT_OK;
+    if (n_blocks > 0x7fffffffull) {
+        hhgt_set_error("lz4: too many blocks");
+        return HHGT_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_lz4_bitplanes, dim3((uint32_t)n_blocks), dim3(128), 0, st, d_src, d_scratch, (uint64_t)slot_bytes, d_csize);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}

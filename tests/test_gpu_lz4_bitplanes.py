@@ -1,0 +1,171 @@
+"""-m gpu: the bit-plane LZ4 encoder (csrc/lz4bits.hip).  Every stream must (a) decode to the plane (oracle decoder,
+through the whole Blosc chunk) and (b) be byte-identical to tools/sim/gapenc_ref.c, the CPU statement of the same
+algorithm — the kernel has no freedom the reference does not have (the hash-table recency relies on the LDS serving
+equal addresses of one ds_wrxchg in lane order, which tools/micro/lds_xchg_order.hip checks on the device)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from haplohyped_varawareml_amd import device as dev
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 4096
+
+
+@pytest.fixture(scope="module")
+def ref(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("gapenc") / "libgapenc.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "sim", "gapenc_ref.c")])
+    L = C.CDLL(so)
+    L.gapenc_ref.restype = C.c_int
+    L.gapenc_ref.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+
+    def encode(plane):
+        out = np.zeros(N + 64, np.uint8)
+        n = L.gapenc_ref(plane.ctypes.data, N, out.ctypes.data)
+        return None if n < 0 else out[:n].copy()
+    return encode
+
+
+def bench_like(rng, n_planes, scale=1.0, S=2504):
+    """planes shaped like bench.py's: per-position frequency log-uniform on [1/(2S), 0.5], times `scale`"""
+    lo = 1.0 / (2 * S)
+    p = np.minimum(lo * (0.5 / lo) ** rng.random((n_planes, N)) * scale, 0.5)
+    return (rng.random((n_planes, N)) < p).astype(np.uint8)
+
+
+def edge_planes():
+    z = np.zeros(N, np.uint8)
+    out = [z.copy()]
+    for pos in ([0], [N - 1], [0, N - 1], [1], [5], [6], [7], [N - 5], [N - 6], [N - 12], [N - 13], [2000], [63], [64], [65],
+                list(range(0, N, 7)), list(range(3, N, 64)), list(range(0, N, 2)), list(range(100, 140)), [10, 11, 12, 30, 31, 32, 50],
+                list(range(0, 1020 * 4, 4)), list(range(0, 1021 * 4, 4))):
+        a = z.copy()
+        a[pos] = 1
+        out.append(a)
+    out.append(np.ones(N, np.uint8))
+    # the same motif repeated at growing distances, motifs that end near the limits
+    a = z.copy()
+    for k, s in enumerate(range(20, N - 40, 97)):
+        a[s] = a[s + 3] = a[s + 9 + (k % 3)] = 1
+    out.append(a)
+    a = z.copy()
+    a[N - 30:N - 20:3] = 1
+    a[N - 11] = a[N - 7] = a[N - 2] = 1
+    out.append(a)
+    return out
+
+
+def streams_of(chunk, typesize, blocksize, nbytes):
+    """per block, per stream: the LZ4 bytes inside a Blosc chunk (16-byte header form)"""
+    hdr = 16 if chunk[0] == 2 and not (chunk[2] & 0x40) else 32
+    nblocks = nbytes // blocksize
+    bst = chunk[hdr:hdr + 4 * nblocks].view("<u4")
+    out = []
+    for b in range(nblocks):
+        p = int(bst[b])
+        for _ in range(typesize):
+            cs = int(chunk[p:p + 4].view("<u4")[0])
+            out.append(chunk[p + 4:p + 4 + cs])
+            p += 4 + cs
+    return out
+
+
+def run_planes(ctx, planes):
+    """planes [2k][4096] -> blocks of 8192 bytes (plane 2b = even bytes, 2b+1 = odd bytes of block b), one chunk"""
+    planes = np.asarray(planes, np.uint8)
+    assert planes.shape[0] % 2 == 0
+    nb = planes.shape[0] // 2
+    raw = np.empty((nb, N, 2), np.uint8)
+    raw[:, :, 0] = planes[0::2]
+    raw[:, :, 1] = planes[1::2]
+    raw = raw.reshape(-1)
+    src = torch.from_numpy(raw).cuda()
+    dst, off, total = ctx.compress(src, raw.size, typesize=2, blocksize=8192, fmt=dev.BLOSC1)
+    chunk = dst[:total].cpu().numpy()
+    assert np.array_equal(oracle.blosc_decompress(chunk), raw), "chunk does not decode to the input"
+    return streams_of(chunk, 2, 8192, raw.size), total
+
+
+def test_lds_exchange_serves_lanes_in_order(tmp_path):
+    exe = str(tmp_path / "xo")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-result", "-o", exe,
+                           os.path.join(ROOT, "tools", "micro", "lds_xchg_order.hip")], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    assert "not 'previous lane with the same key': 0" in out, out
+
+
+@pytest.mark.parametrize("scale,seed", [(1.0, 1), (1.0, 2), (0.25, 3), (4.0, 4), (0.02, 5)])
+def test_random_planes_match_the_reference(ctx, ref, scale, seed):
+    rng = np.random.default_rng(seed)
+    planes = bench_like(rng, 128, scale)
+    got, total = run_planes(ctx, planes)
+    n_ref = 0
+    for k, pl in enumerate(planes):
+        want = ref(pl)
+        if want is None or want.size >= N:      # left to the byte-wise encoder / stored verbatim
+            continue
+        n_ref += 1
+        assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref ({got[k].size} vs {want.size} bytes)"
+        assert np.array_equal(oracle.lz4_decompress(got[k], N), pl)
+    assert n_ref >= 120
+    if scale == 1.0:
+        assert planes.size / total > 5.0          # the ratio the byte-wise encoder reaches on such planes is 5.12
+
+
+def test_edge_planes(ctx, ref):
+    planes = edge_planes()
+    if len(planes) % 2:
+        planes.append(np.zeros(N, np.uint8))
+    got, _ = run_planes(ctx, planes)
+    for k, pl in enumerate(planes):
+        want = ref(pl)
+        back = pl if got[k].size == N else oracle.lz4_decompress(got[k], N)
+        assert np.array_equal(back, pl), f"edge plane {k}"
+        if want is not None and want.size < N:
+            assert np.array_equal(got[k], want), f"edge plane {k}: differs from gapenc_ref"
+
+
+def test_non_binary_and_dense_planes_fall_back(ctx, ref):
+    """a byte > 1 (missing call -9 = 0xF7) or more than 1020 ones: the byte-wise encoder codes the stream — mixed
+    with bit-plane streams in the same block and chunk"""
+    rng = np.random.default_rng(9)
+    planes = bench_like(rng, 16)
+    planes[3, 100] = 0xF7
+    planes[4, rng.integers(0, N, 300)] = 0xF7
+    planes[7] = rng.integers(0, 2, N)
+    planes[10] = rng.integers(0, 256, N)
+    assert ref(planes[3]) is None and ref(planes[7]) is None
+    got, _ = run_planes(ctx, planes)
+    for k, pl in enumerate(planes):
+        back = pl if got[k].size == N else oracle.lz4_decompress(got[k], N)
+        assert np.array_equal(back, pl), k
+    assert np.array_equal(got[0], ref(planes[0])) and np.array_equal(got[2], ref(planes[2]))
+
+
+def test_bitplanes_switch(ctx):
+    """HHGT_LZ4_BITPLANES=0 keeps the byte-wise encoder: both decode, sizes differ"""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from haplohyped_varawareml_amd import device as dev
+from oracle import oracle
+ctx = dev.Context(0)
+rng = np.random.default_rng(1)
+raw = (rng.random(64 * 8192 * 2) < 0.05).astype(np.uint8)
+dst, off, total = ctx.compress(torch.from_numpy(raw).cuda(), raw.size, typesize=2, blocksize=8192)
+assert np.array_equal(oracle.blosc_decompress(dst[:total].cpu().numpy()), raw)
+print(total)
+""" % ROOT
+    sizes = []
+    for v in ("1", "0"):
+        env = dict(os.environ, HHGT_LZ4_BITPLANES=v)
+        sizes.append(int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.split()[-1]))
+    assert sizes[0] != sizes[1] and 0.8 < sizes[0] / sizes[1] < 1.25

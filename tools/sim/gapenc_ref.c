@@ -1,0 +1,130 @@
+// gapenc_ref.c — CPU statement of the bit-plane LZ4 encoder (csrc/lz4bits.hip, k_lz4_bitplanes), decision for
+// decision, so that the kernel's streams can be compared byte for byte (tests/test_gpu_lz4_bitplanes.py) and its
+// ratio studied without a GPU (tools/sim/gapenc.c is the exploration this came out of).  Not part of the product and
+// not an oracle of the reference: whether a stream is VALID is checked by decoding it (liblz4 / oracle decoder).
+//
+// Input: a plane of n = 4096 bytes, all 0 or 1.  Walks the ONES q_0 < q_1 < ... (a virtual one at -1 in front and
+// one at n behind).  P[j+1] = q_j + 1.  For every one j:
+//   * context = bits q .. q+11, hashed into a 256-entry table of one indices; the table is updated one by one in
+//     stream order (on the GPU: one ds_wrxchg_rtn_b32 per 64 ones — the LDS serves equal addresses in lane order)
+//   * candidate jc = previous one with that hash.  Forward length from the GAPS: while the gaps behind the two ones
+//     are equal (at most 8 of them) take gap + 1, then 1 + the smaller gap.  costR = what coding the covered ones
+//     as literals (+ offset-1 runs for gaps >= 7) would take; tailz = zeros left of the last covered one's gap
+//   * pulled back over nb = min(8, zeros in front of q, zeros in front of the candidate) literal zeros
+//   * taken (hv) iff cheaper than costR, forward part >= 4, total >= 6, q <= mflimit
+//   * E = end of what the one codes (match end, else q + 1); nxt = first one at or behind E
+// The parse follows nxt from the virtual one.  Every visited one emits its match M (start clamped to the end of the
+// previous sequence) and a tail run T (offset 1) over the zeros from E (+1 if byte E-1 is a one, or E = 0) to the
+// next one, if >= 6 long.
+#include <stdint.h>
+#include <string.h>
+
+#define N_MAXONES 1020
+#define HLOG 8
+#define MINM 6
+#define BACK 8
+#define STEPS 8
+
+static int put_len(uint8_t *out, int op, int r)
+{
+    while (r >= 255) { out[op++] = 255; r -= 255; }
+    out[op++] = (uint8_t)r;
+    return op;
+}
+
+static int put_seq(const uint8_t *in, uint8_t *out, int op, int anchor, int start, int len, int off)
+{
+    const int ll = start - anchor, ml = len - 4;
+    out[op++] = (uint8_t)(((ll < 15 ? ll : 15) << 4) | (ml < 15 ? ml : 15));
+    if (ll >= 15) op = put_len(out, op, ll - 15);
+    memcpy(out + op, in + anchor, (size_t)ll);
+    op += ll;
+    out[op++] = (uint8_t)(off & 0xFF);
+    out[op++] = (uint8_t)(off >> 8);
+    if (ml >= 15) op = put_len(out, op, ml - 15);
+    return op;
+}
+
+// returns the compressed size, or -1 if the plane is not handled by the bit-plane path (a byte > 1, too many ones)
+int gapenc_ref(const uint8_t *in, int n, uint8_t *out)
+{
+    static __thread int P[4096 + 4];
+    int m = 0;
+    P[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (in[i] > 1) return -1;
+        if (in[i]) {
+            if (m >= N_MAXONES) return -1;
+            P[1 + m++] = i + 1;
+        }
+    }
+    P[m + 1] = P[m + 2] = n + 1;
+    uint32_t tab[1 << HLOG];
+    memset(tab, 0, sizeof(tab));
+    const int mflimit = n - 12, matchlimit = n - 5;
+    static __thread int E[4100], nxt[4100], ms[4100], hv_[4100], off_[4100];
+    for (int j = -1; j < m; ++j) {
+        const int q = P[j + 1] - 1;
+        int hv = 0, len = 0, nb = 0, c = 0;
+        if (j >= 0 && q + 12 <= n) {
+            uint32_t ctx = 0;
+            for (int k = 0; k < 12; ++k) ctx |= (uint32_t)in[q + k] << k;
+            const uint32_t idx = (ctx * 2654435761u) >> (32 - HLOG);
+            const int jc = (int)tab[idx] - 1;
+            tab[idx] = (uint32_t)(j + 1);
+            if (jc >= 0) {
+                c = P[jc + 1] - 1;
+                int a = j, b = jc, pa = q + 1, pb = c + 1, costR = 0, tailz = 0;
+                for (int s = 0;; ++s) {
+                    const int na = P[a + 2], nbn = P[b + 2];
+                    const int ga = na - pa - 1, gb = nbn - pb - 1;
+                    costR += 1 + (ga >= MINM + 1 ? 4 : ga);
+                    if (ga != gb || a + 1 >= m || s >= STEPS) {
+                        const int z = ga < gb ? ga : gb;
+                        len += 1 + z;
+                        tailz = ga - z;
+                        break;
+                    }
+                    len += 1 + ga;
+                    ++a; ++b; pa = na; pb = nbn;
+                }
+                const int gq = q + 1 - P[j] - 1, gc = c + 1 - P[jc] - 1;
+                nb = gq < gc ? gq : gc;
+                if (nb > BACK) nb = BACK;
+                const int costH = 3 + (len + nb >= 19 ? 1 : 0) - nb + (tailz >= MINM ? 3 : tailz);
+                int end = q + len;
+                if (end > matchlimit) end = matchlimit;
+                hv = costH < costR && end - q >= 4 && end - (q - nb) >= MINM && q <= mflimit;
+                len = end - q;
+            }
+        }
+        const int e = hv ? q + len : q + 1;
+        E[j + 1] = e; ms[j + 1] = q - nb; hv_[j + 1] = hv; off_[j + 1] = q - c;
+        int t = j + 1;
+        while (t < m && P[t + 1] - 1 < e) ++t;
+        nxt[j + 1] = t;
+    }
+    int op = 0, prev_end = 0;
+    for (int j = -1; j < m; j = nxt[j + 1]) {
+        const int e = E[j + 1];
+        if (hv_[j + 1]) {
+            int st = ms[j + 1];
+            if (st < prev_end) st = prev_end;
+            op = put_seq(in, out, op, prev_end, st, e - st, off_[j + 1]);
+            prev_end = e;
+        }
+        const int rs = e + ((e == 0 || in[e - 1]) ? 1 : 0);
+        int re = P[nxt[j + 1] + 1] - 1;
+        if (re > matchlimit) re = matchlimit;
+        if (re - rs >= MINM && rs <= mflimit) {
+            op = put_seq(in, out, op, prev_end, rs, re - rs, 1);
+            prev_end = re;
+        }
+    }
+    const int ll = n - prev_end;
+    out[op++] = (uint8_t)((ll < 15 ? ll : 15) << 4);
+    if (ll >= 15) op = put_len(out, op, ll - 15);
+    memcpy(out + op, in + prev_end, (size_t)ll);
+    op += ll;
+    return op;
+}
