@@ -137,7 +137,8 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
                 const uint32_t x = d[i];
                 nb0 |= x & 0x00FE00FEu;
                 nb1 |= x & 0xFE00FE00u;
-                const uint32_t y = x | (x >> 15);   // bits 0,1: plane-0 bytes; bits 8,9: plane-1 bytes
+                const uint32_t xm = x & 0x01010101u;   // (a byte > 1 in one plane must not leak into the other plane's bits)
+                const uint32_t y = xm | (xm >> 15);    // bits 0,1: plane-0 bytes; bits 8,9: plane-1 bytes
                 acc0 |= (y & 3u) << (2 * (4 * k + i));
                 acc1 |= ((y >> 8) & 3u) << (2 * (4 * k + i));
             }
