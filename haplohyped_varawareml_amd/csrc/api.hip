@@ -105,7 +105,7 @@ extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
     DevBuf *bufs[] = {&c->slots, &c->counts, &c->prefix, &c->nl, &c->scan_tmp, &c->l_soff, &c->l_lend, &c->l_pos,
                       &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff,
                       &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_names,
-                      &c->counters, &c->cursor, &c->result, &c->lz_scratch, &c->lz_csize, &c->fr_bsize, &c->fr_csize,
+                      &c->counters, &c->cursor, &c->result, &c->lz_scratch, &c->lz_csize, &c->lz_marked, &c->fr_bsize, &c->fr_csize,
                       &c->fr_flags, &c->dec_bad, &c->oh_ovl, &c->oh_lut, &c->crc_x2n};
     for (DevBuf *b : bufs) b->release();
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -672,13 +672,15 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
     const uint64_t n_streams = n_chunks * nblocks * nwaves;
     TRY(c->lz_scratch.ensure((size_t)n_streams * slot));
     TRY(c->lz_csize.ensure((size_t)n_streams * 4));
+    TRY(c->lz_marked.ensure(((size_t)n_streams + 4) * 4));   // [0]: count, [1..]: queued blocks (streams >= blocks)
     TRY(c->fr_bsize.ensure((size_t)n_chunks * nblocks * 4));
     TRY(c->fr_csize.ensure(((size_t)n_chunks + 1) * 8));
     TRY(c->fr_flags.ensure((size_t)n_chunks * 4));
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
         TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize,
-                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel <= 2 ? 1 : (c->clevel >= 7 ? 2 : 0), st));
+                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel, c->lz_marked.as<uint32_t>() + 1,
+                              c->lz_marked.as<uint32_t>(), st));
         t.stop();
     }
     {

@@ -97,7 +97,7 @@ struct hhgt_ctx {
     DevBuf cursor;         // uint64: v_base of the synchronous hhgt_encode_text (the asynchronous form gets the caller's)
     DevBuf result;         // hhgt_encode_result staging of the asynchronous form
     // compress workspaces
-    DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut, crc_x2n;
+    DevBuf lz_scratch, lz_csize, lz_marked, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut, crc_x2n;
     bool crc_x2n_ready = false;
     // pinned host mirror for counters
     DevCounters *h_counters = nullptr;
@@ -168,11 +168,11 @@ int launch_pad_tail_cursor(LayoutDev lay, const uint64_t *d_cursor, int8_t *d_G,
 // lz4.hip
 size_t lz4_slot_bytes(int neblock);
 int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int fast,
-                      hipStream_t st);
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
+                      uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st);
 // lz4bits.hip: typesize 2, 8 KiB blocks; streams it cannot code get csize = 0xFFFFFFFF
 int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
-                         hipStream_t st);
+                         uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st);
 // frame.hip
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src,
                  uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,

@@ -649,22 +649,22 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
                                                      uint64_t chunk_nbytes, uint32_t typesize, uint32_t blocksize,
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
-                                                     uint32_t *__restrict__ csize)
+                                                     uint32_t *__restrict__ csize, const uint32_t *__restrict__ marked,
+                                                     const uint32_t *__restrict__ n_marked)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
-    // algo bit 8: only the streams the bit-plane encoder (lz4bits.hip) left marked (csize == 0xFFFFFFFF) are coded
+    // algo bit 8: list mode — only the blocks the bit-plane encoder (lz4bits.hip) queued, and of those only the streams it
+    // left marked (csize == 0xFFFFFFFF), are coded; the (small, fixed) grid walks the list
     const bool only_marked = (algo & 0x100u) != 0u;
-    if (only_marked) {
-        bool any = false;
-        for (uint32_t w = 0; w < nwaves; ++w) any = any || csize[(uint64_t)blockIdx.x * nwaves + w] == 0xFFFFFFFFu;
-        if (!any) return;
-    }
+    const uint32_t n_list = only_marked ? *n_marked : 1u;
+    for (uint32_t it = blockIdx.x; it < (only_marked ? n_list : blockIdx.x + 1u); it += gridDim.x) {
+    const uint32_t bid = only_marked ? marked[it] : blockIdx.x;
     // wave index through readfirstlane: everything derived from it (stream base, output slot) stays in SGPRs,
     // so the byte stores below use the SGPR-base + 32-bit-offset addressing form
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    const uint64_t chunk = blockIdx.x / nblocks;
-    const uint32_t b = blockIdx.x - (uint32_t)(chunk * nblocks);
+    const uint64_t chunk = bid / nblocks;
+    const uint32_t b = bid - (uint32_t)(chunk * nblocks);
     const uint64_t boff = (uint64_t)b * blocksize;
     const uint32_t bsize = (uint32_t)(chunk_nbytes - boff < blocksize ? chunk_nbytes - boff : blocksize);
     const bool leftover = bsize != blocksize;
@@ -708,10 +708,11 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     }
     __syncthreads();
     // ---- phase B: one wave per stream
-    if (only_marked && csize[(uint64_t)blockIdx.x * nwaves + wave] != 0xFFFFFFFFu) return;
-    if (wave < nstreams) {
+    if (only_marked && csize[(uint64_t)bid * nwaves + wave] != 0xFFFFFFFFu) {
+        // this stream of the block was coded by the bit-plane encoder
+    } else if (wave < nstreams) {
         const uint8_t *in = data + (size_t)wave * pstride;
-        const uint64_t sidx = (uint64_t)blockIdx.x * nwaves + wave;
+        const uint64_t sidx = (uint64_t)bid * nwaves + wave;
         uint8_t *out = scratch + sidx * slot_bytes;
         uint16_t *tb = tabs + (size_t)wave * ((1u << hashlog) + 2u);
         // sequence queue: 64 entries per wave, 8-aligned after the tables (offset arithmetic keeps the LDS address space)
@@ -728,22 +729,29 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
         }
         if (lane == 0) csize[sidx] = cs;
     } else if (lane == 0) {
-        csize[(uint64_t)blockIdx.x * nwaves + wave] = 0u;
+        csize[(uint64_t)bid * nwaves + wave] = 0u;
+    }
+    if (only_marked) __syncthreads();   // the next block of the list reuses the LDS
     }
 }
 
 int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int fast,
-                      hipStream_t st)
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
+                      uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st)
 {
+    const int fast = clevel <= 2 ? 1 : (clevel >= 7 ? 2 : 0);
     // the bit-plane encoder (lz4bits.hip) takes the case the path is built for — typesize 2, 8 KiB blocks, default
     // effort — and marks the streams it cannot code (a byte > 1, very dense planes); this kernel then only runs those.
     // HHGT_LZ4_BITPLANES=0 keeps everything on the byte-wise encoder.
     static const bool bp_env = !(getenv("HHGT_LZ4_BITPLANES") && atoi(getenv("HHGT_LZ4_BITPLANES")) == 0);
-    const bool bitplanes = bp_env && fast == 0 && typesize == 2 && blocksize == 8192 && chunk_nbytes % 8192 == 0 &&
-                           (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0 && slot_bytes >= 4128;
+    const bool bitplanes = bp_env && typesize == 2 && blocksize == 8192 && chunk_nbytes % 8192 == 0 &&
+                           (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0 && slot_bytes >= 4128 && d_marked && d_n_marked;
     if (bitplanes) {
-        const int rc = launch_lz4_bitplanes(d_src, n_chunks * (chunk_nbytes / 8192), d_scratch, slot_bytes, d_csize, st);
+        // effort: candidates tried per one along the hash chain (clevel 1-2: none, offset-1 runs only)
+        static const int depth_env = getenv("HHGT_LZ4_DEPTH") ? atoi(getenv("HHGT_LZ4_DEPTH")) : -1;
+        const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 24);
+        const int rc = launch_lz4_bitplanes(d_src, n_chunks * (chunk_nbytes / 8192), d_scratch, slot_bytes, d_csize, d_marked,
+                                            d_n_marked, depth, st);
         if (rc != HHGT_OK) return rc;
     }
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
@@ -794,8 +802,10 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
     // HHGT_LZ4_ALGO: 6 = window-parallel encoder with batched emission (default), 1 = the simple first version (A/B)
     static const uint32_t algo_env = getenv("HHGT_LZ4_ALGO") ? (uint32_t)atoi(getenv("HHGT_LZ4_ALGO")) : 6u;
     const uint32_t algo = algo_env | (bitplanes ? 0x100u : 0u);
-    const uint64_t grid = n_chunks * nblocks;
+    uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
+    // list mode: a fixed grid (enough workgroups to fill the chip) walks the queued blocks
+    if (bitplanes && grid > 256u * 14u) grid = 256u * 14u;
     if (grid > 0x7fffffffull) {
         hhgt_set_error("lz4: too many blocks");
         return HHGT_ERR_ARG;
@@ -813,7 +823,7 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
 #define LZ_LAUNCH(MWV, ALG)                                                                                          \
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
-                       (uint64_t)slot_bytes, d_csize)
+                       (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)
     if ((algo & 0xFFu) == 1u) LZ_LAUNCH(0, 1);

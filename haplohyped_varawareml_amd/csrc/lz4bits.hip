@@ -27,7 +27,8 @@
 #include "common.h"
 
 #define BP_N 4096
-#define BP_MAXONES 1020
+#define BP_MAXONES 764
+#define BP_STAGE 1024
 #define BP_HLOG 8
 #define BP_MINM 6
 #define BP_BACK 8
@@ -35,32 +36,53 @@
 #define BP_MFLIMIT (BP_N - 12)
 #define BP_MATCHLIMIT (BP_N - 5)
 
-struct BpLds {
+template <bool CHAIN> struct BpLds {
     uint32_t bm[132];                // bit map of the plane: 128 dwords + zero padding
     uint32_t tab[1 << BP_HLOG];      // context hash -> one index + 1
     uint32_t flag[68];               // pointer-doubling marks of a window
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
     uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
+    uint16_t chain[CHAIN ? BP_MAXONES + 8 : 4];   // chain[j + 1] = (previous one with the same context hash) + 1, 0 = none
+    uint8_t stage[BP_STAGE];         // output staged here, written out in coalesced dwords
 };
 
-__device__ __forceinline__ uint32_t bp_scan_sum(uint32_t v, uint32_t lane)   // inclusive
+// wave-wide inclusive scans on DPP row shifts (no LDS round trips): sum and max of non-negative values
+__device__ __forceinline__ uint32_t bp_row_shr(uint32_t x, int d)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
+    switch (d) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
     }
-    return v;
 }
 
-__device__ __forceinline__ uint32_t bp_scan_max(uint32_t v, uint32_t lane)   // inclusive
+__device__ __forceinline__ uint32_t bp_scan_sum(uint32_t x, uint32_t lane)   // inclusive
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v = v > t ? v : t;
-    }
-    return v;
+    x += bp_row_shr(x, 1);
+    x += bp_row_shr(x, 2);
+    x += bp_row_shr(x, 4);
+    x += bp_row_shr(x, 8);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 15);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 31) + t0;
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 47) + t1;
+    const uint32_t row = lane >> 4;
+    return x + (row == 0u ? 0u : (row == 1u ? t0 : (row == 2u ? t1 : t2)));
+}
+
+__device__ __forceinline__ uint32_t bp_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+__device__ __forceinline__ uint32_t bp_scan_max(uint32_t x, uint32_t lane)   // inclusive
+{
+    x = bp_max(x, bp_row_shr(x, 1));
+    x = bp_max(x, bp_row_shr(x, 2));
+    x = bp_max(x, bp_row_shr(x, 4));
+    x = bp_max(x, bp_row_shr(x, 8));
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 15);
+    const uint32_t t1 = bp_max((uint32_t)__builtin_amdgcn_readlane((int)x, 31), t0);
+    const uint32_t t2 = bp_max((uint32_t)__builtin_amdgcn_readlane((int)x, 47), t1);
+    const uint32_t row = lane >> 4;
+    return bp_max(x, row == 0u ? 0u : (row == 1u ? t0 : (row == 2u ? t1 : t2)));
 }
 
 // 32 bits of the map starting at bit q (0 <= q < 4096 + 96)
@@ -73,8 +95,9 @@ __device__ __forceinline__ uint32_t bp_bits(const volatile uint32_t *bm, uint32_
 
 __device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return x >= 15u ? (x - 15u) / 255u + 1u : 0u; }
 
-// one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off)
-__device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t *__restrict__ out, uint32_t at, uint32_t anchor,
+// one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off).  `out` is the
+// staging area in LDS or, for a window too large for it, the stream's slot in global memory (generic pointer).
+__device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t *out, uint32_t at, uint32_t anchor,
                                            uint32_t start, uint32_t len, uint32_t off, bool on)
 {
     const uint32_t ll = on ? start - anchor : 0u, ml = len - 4u;
@@ -88,15 +111,13 @@ __device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t 
         }
     }
     const uint32_t lit = at + 1u + llx;
-    // literals: lockstep over the longest run of the wave; 32 bits of the map per refill
-    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < ll) != 0ull; k += 32u) {
+    // literals: lockstep over the longest run of the wave (typically 1-3 bytes); 32 bits of the map per refill
+    uint32_t b = 0;
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < ll) != 0ull; ++k) {
         if (k < ll) {
-            uint32_t b = bp_bits(bm, anchor + k);
-            const uint32_t cnt = ll - k < 32u ? ll - k : 32u;
-            for (uint32_t t = 0; t < cnt; ++t) {
-                out[lit + k + t] = (uint8_t)(b & 1u);
-                b >>= 1;
-            }
+            if ((k & 31u) == 0u) b = bp_bits(bm, anchor + k);
+            out[lit + k] = (uint8_t)(b & 1u);
+            b >>= 1;
         }
     }
     if (on) {
@@ -111,12 +132,30 @@ __device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t 
     }
 }
 
-// grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
-__global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, uint8_t *__restrict__ scratch,
-                                                          uint64_t slot_bytes, uint32_t *__restrict__ csize)
+// staged bytes [0, n) -> global, whole dwords coalesced, the last 1-3 bytes singly
+__device__ __forceinline__ void bp_flush(const uint8_t *stage, uint8_t *__restrict__ dst, uint32_t n, uint32_t lane)
 {
-    __shared__ BpLds lds[2];
+    struct __attribute__((packed)) PU32 {
+        uint32_t v;
+    };
+    const uint32_t nd = n >> 2;
+    for (uint32_t i = lane; i < nd; i += 64u) reinterpret_cast<PU32 *>(dst + 4u * i)->v = reinterpret_cast<const uint32_t *>(stage)[i];
+    const uint32_t t = (nd << 2) + lane;
+    if (t < n) dst[t] = stage[t];
+}
+
+// grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
+// DEPTH = candidates tried per one along the hash chain (1: the table's entry only; 0: no hash matches at all,
+// offset-1 runs only — the fastest level)
+template <int DEPTH>
+__global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, uint8_t *__restrict__ scratch,
+                                                          uint64_t slot_bytes, uint32_t *__restrict__ csize,
+                                                          uint32_t *__restrict__ marked, uint32_t *__restrict__ n_marked)
+{
+    constexpr bool CHAIN = DEPTH > 1;
+    __shared__ BpLds<CHAIN> lds[2];
     __shared__ uint32_t nonbin[2][2];
+    __shared__ uint32_t queued;   // the block goes into the byte-wise encoder's list once, whichever wave asks first
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint8_t *blk = src + (uint64_t)blockIdx.x * 8192u;
 
@@ -151,11 +190,12 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             nonbin[wave][1] = b1 != 0ull;
         }
         if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
+        if (threadIdx.x == 0) queued = 0u;
     }
     __syncthreads();
 
     // ---- phase B: wave w codes plane w
-    BpLds &S = lds[wave];
+    BpLds<CHAIN> &S = lds[wave];
     volatile uint32_t *bm = S.bm;
     volatile uint16_t *P = S.P;
     volatile uint16_t *wpre = S.wpre;
@@ -168,7 +208,10 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     const uint32_t incl = bp_scan_sum(cnt, lane);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if ((nonbin[0][wave] | nonbin[1][wave]) != 0u || m > BP_MAXONES) {
-        if (lane == 0) csize[sidx] = 0xFFFFFFFFu;   // left to the byte-wise encoder
+        if (lane == 0) {   // left to the byte-wise encoder: mark the stream, queue its block (once: two workgroups on one
+            csize[sidx] = 0xFFFFFFFFu;   // block would write two different valid encodings into the same slot)
+            if (atomicExch(&queued, 1u) == 0u) marked[atomicAdd(n_marked, 1u)] = blockIdx.x;
+        }
         return;
     }
     wpre[lane] = (uint16_t)(incl - cnt);
@@ -193,7 +236,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
 #pragma unroll
     for (int k = 0; k < (1 << BP_HLOG) / 64; ++k) S.tab[64 * k + lane] = 0u;
 
-    uint32_t op = 0, prev_end = 0;
+    uint32_t gop = 0, sop = 0, prev_end = 0;   // bytes written to global / staged; end of the last sequence
     int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
     for (int jw = -1; jw < (int)m; jw += 64) {
         const int j = jw + (int)lane;
@@ -203,53 +246,101 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         const uint32_t qp1 = jj ? P[jj - 1u] : 0u;
         const int q = (int)q1 - 1;
         // ---- hash table: context of 12 bits at the one; exact recency through the LDS's lane order
-        const bool can = valid && j >= 0 && q + 12 <= BP_N;
+        const bool can = DEPTH > 0 && valid && j >= 0 && q + 12 <= BP_N;
         uint32_t jc1 = 0;
         if (can) {
             const uint32_t ctx = bp_bits(bm, (uint32_t)q) & 0xFFFu;
             const uint32_t idx = (ctx * 2654435761u) >> (32 - BP_HLOG);
             jc1 = atomicExch(&S.tab[idx], (uint32_t)(j + 1));
+            if (CHAIN) S.chain[jj] = (uint16_t)jc1;   // what this one replaced: the next candidate down the chain
         }
-        // ---- candidate: forward length from the gaps
-        const bool have = can && jc1 != 0u;
-        uint32_t len = 0, costR = 0, tailz = 0;
-        const uint32_t c1 = have ? (uint32_t)P[jc1] : 0u;   // P[jc + 1] with jc = jc1 - 1
-        {
-            uint32_t a = jj, b = jc1, pa = q1, pb = c1;
-            bool act = have;
-            for (int s = 0; s <= BP_STEPS; ++s) {
-                if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-                if (act) {
-                    const uint32_t na = P[a + 1u], nbn = P[b + 1u];
-                    const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
-                    costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
-                    if (ga != gb || a >= m || s >= BP_STEPS) {   // a = j + 1: "a + 1 >= m" of the reference
-                        const uint32_t z = ga < gb ? ga : gb;
-                        len += 1u + z;
-                        tailz = ga - z;
-                        act = false;
-                    } else {
-                        len += 1u + ga;
-                        ++a;
-                        ++b;
-                        pa = na;
-                        pb = nbn;
+        // ---- candidates: forward length from the gaps; DEPTH of them along the chain, the one that saves most wins
+        const uint32_t gq = q1 - qp1 - 1u;
+        uint32_t len = 0, nb = 0, c1 = 0;
+        bool hv = false;
+        int best_gain = -100000;
+#pragma unroll 1
+        for (int dpt = 0; dpt < (DEPTH > 0 ? DEPTH : 1); ++dpt) {
+            const bool have = can && jc1 != 0u;
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+            // Everything the first three gap comparisons need is fetched in ONE LDS round trip (the kernel is bound by
+            // dependent LDS latencies, not by issue): three P entries behind each of the two ones, the entry in front
+            // of the candidate, the next link of the chain.  Most candidates are decided within these.
+            const uint32_t jq = have ? jc1 : 1u;
+            const uint32_t cc1 = P[jq];                    // P[jc + 1] with jc = jc1 - 1
+            const uint32_t cp1 = P[jq - 1u];
+            const uint32_t b1 = P[jq + 1u], b2 = P[jq + 2u], b3 = P[jq + 3u];
+            const uint32_t a1 = qn1, a2 = P[jj + 2u], a3 = P[jj + 3u];
+            uint32_t nextc = 0;
+            if (CHAIN) nextc = S.chain[jq];
+            uint32_t clen = 0, costR = 0, tailz = 0;
+            {
+                uint32_t a = jj, b = jc1, pa = q1, pb = cc1;
+                bool act = have;
+                // steps 0..2 from registers
+                const uint32_t av[3] = {a1, a2, a3}, bv[3] = {b1, b2, b3};
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    if (act) {
+                        const uint32_t na = av[s], nbn = bv[s];
+                        const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
+                        costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
+                        if (ga != gb || a >= m) {
+                            const uint32_t z = ga < gb ? ga : gb;
+                            clen += 1u + z;
+                            tailz = ga - z;
+                            act = false;
+                        } else {
+                            clen += 1u + ga;
+                            ++a;
+                            ++b;
+                            pa = na;
+                            pb = nbn;
+                        }
+                    }
+                }
+                // longer agreements: one round trip per further gap
+                for (int s = 3; s <= BP_STEPS; ++s) {
+                    if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                    if (act) {
+                        const uint32_t na = P[a + 1u], nbn = P[b + 1u];
+                        const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
+                        costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
+                        if (ga != gb || a >= m || s >= BP_STEPS) {   // a = j + 1: "a + 1 >= m" of the reference
+                            const uint32_t z = ga < gb ? ga : gb;
+                            clen += 1u + z;
+                            tailz = ga - z;
+                            act = false;
+                        } else {
+                            clen += 1u + ga;
+                            ++a;
+                            ++b;
+                            pa = na;
+                            pb = nbn;
+                        }
                     }
                 }
             }
-        }
-        uint32_t nb = 0;
-        bool hv = false;
-        if (have) {
-            const uint32_t gq = q1 - qp1 - 1u, gc = c1 - (uint32_t)P[jc1 - 1u] - 1u;
-            nb = gq < gc ? gq : gc;
-            nb = nb < BP_BACK ? nb : BP_BACK;
-            const uint32_t costH = 3u + (len + nb >= 19u ? 1u : 0u) - nb + (tailz >= BP_MINM ? 3u : tailz);
-            uint32_t end = (uint32_t)q + len;
-            end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
-            // signed compares: costH may wrap below zero when many zeros are pulled in
-            hv = (int)costH < (int)costR && (int)end - q >= 4 && (int)end - (q - (int)nb) >= BP_MINM && q <= BP_MFLIMIT;
-            len = end - (uint32_t)q;
+            if (have) {
+                const uint32_t gc = cc1 - cp1 - 1u;
+                uint32_t cnb = gq < gc ? gq : gc;
+                cnb = cnb < BP_BACK ? cnb : BP_BACK;
+                const uint32_t costH = 3u + (clen + cnb >= 19u ? 1u : 0u) - cnb + (tailz >= BP_MINM ? 3u : tailz);
+                uint32_t end = (uint32_t)q + clen;
+                end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
+                // signed compares: costH may go below zero when many zeros are pulled in
+                const int gain = (int)costR - (int)costH;
+                const bool ok = gain > 0 && (int)end - q >= 4 && (int)end - (q - (int)cnb) >= BP_MINM && q <= BP_MFLIMIT;
+                if (ok && gain > best_gain) {
+                    best_gain = gain;
+                    hv = true;
+                    len = end - (uint32_t)q;
+                    nb = cnb;
+                    c1 = cc1;
+                }
+            }
+            if (!CHAIN) break;
+            jc1 = have ? nextc : 0u;
         }
         const uint32_t E = hv ? (uint32_t)q + len : (uint32_t)(q + 1);   // end of what this one codes (0 for the virtual one)
         // first one at or behind E: ones in front of bit E of the map
@@ -305,44 +396,75 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         const uint32_t szM = onM ? 3u + bp_len_ext(llM) + llM + bp_len_ext(lenM - 4u) : 0u;
         const uint32_t szT = onT ? 3u + bp_len_ext(llT) + llT + bp_len_ext(lenT - 4u) : 0u;
         const uint32_t sincl = bp_scan_sum(szM + szT, lane);
-        const uint32_t at = op + sincl - (szM + szT);
-        bp_put_seq(bm, out, at, pe, ms, lenM, (uint32_t)q + 1u - c1, onM);
-        bp_put_seq(bm, out, at + szM, pe2, rs, lenT, 1u, onT);
-        op += (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        // the window's bytes go to the staging area; what is staged leaves in coalesced dwords when the next window
+        // would not fit (a window larger than the whole area is written to global memory directly)
+        if (sop + total > BP_STAGE) {
+            bp_flush(S.stage, out + gop, sop, lane);
+            gop += sop;
+            sop = 0;
+        }
+        const bool direct = total > BP_STAGE;
+        uint8_t *dstp = direct ? out + gop : static_cast<uint8_t *>(S.stage) + sop;
+        const uint32_t at = sincl - (szM + szT);
+        bp_put_seq(bm, dstp, at, pe, ms, lenM, q1 - c1, onM);
+        bp_put_seq(bm, dstp, at + szM, pe2, rs, lenT, 1u, onT);
+        if (direct) gop += total;
+        else sop += total;
         const uint32_t fmax = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
         prev_end = fmax > prev_end ? fmax : prev_end;
     }
     // ---- last literals
     {
         const uint32_t ll = BP_N - prev_end, llx = bp_len_ext(ll);
+        if (sop + 1u + llx + ll > BP_STAGE) {
+            bp_flush(S.stage, out + gop, sop, lane);
+            gop += sop;
+            sop = 0;
+        }
+        const bool direct = 1u + llx + ll > BP_STAGE;
+        uint8_t *dstp = direct ? out + gop : static_cast<uint8_t *>(S.stage) + sop;
         if (lane == 0) {
-            out[op] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
+            dstp[0] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
             uint32_t r = ll - 15u;
             for (uint32_t k = 0; k < llx; ++k) {
-                out[op + 1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
+                dstp[1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
                 r -= 255u;
             }
         }
-        const uint32_t lit = op + 1u + llx;
-        for (uint32_t k = lane; k < ll; k += 64u) out[lit + k] = (uint8_t)(bp_bits(bm, prev_end + k) & 1u);
-        op = lit + ll;
+        for (uint32_t k = lane; k < ll; k += 64u) dstp[1u + llx + k] = (uint8_t)(bp_bits(bm, prev_end + k) & 1u);
+        if (direct) gop += 1u + llx + ll;
+        else sop += 1u + llx + ll;
     }
+    uint32_t op = gop + sop;
     if (op >= BP_N) {   // incompressible: Blosc stores the (shuffled) stream verbatim
         for (uint32_t k = lane; k < BP_N; k += 64u) out[k] = (uint8_t)(bp_bits(bm, k) & 1u);
         op = BP_N;
+    } else {
+        bp_flush(S.stage, out + gop, sop, lane);
     }
     if (lane == 0) csize[sidx] = op;
 }
 
 int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
-                         hipStream_t st)
+                         uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st)
 {
     if (n_blocks == 0) return HHGT_OK;
     if (n_blocks > 0x7fffffffull) {
         hhgt_set_error("lz4: too many blocks");
         return HHGT_ERR_ARG;
     }
-    hipLaunchKernelGGL(k_lz4_bitplanes, dim3((uint32_t)n_blocks), dim3(128), 0, st, d_src, d_scratch, (uint64_t)slot_bytes, d_csize);
+    HIP_TRY(hipMemsetAsync(d_n_marked, 0, 4, st));
+#define BP_LAUNCH(D)                                                                                                       \
+    hipLaunchKernelGGL((k_lz4_bitplanes<D>), dim3((uint32_t)n_blocks), dim3(128), 0, st, d_src, d_scratch, (uint64_t)slot_bytes, \
+                       d_csize, d_marked, d_n_marked)
+    if (depth <= 0) BP_LAUNCH(0);
+    else if (depth == 1) BP_LAUNCH(1);
+    else if (depth == 2) BP_LAUNCH(2);
+    else if (depth <= 4) BP_LAUNCH(4);
+    else if (depth <= 8) BP_LAUNCH(8);
+    else BP_LAUNCH(24);
+#undef BP_LAUNCH
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

@@ -25,11 +25,11 @@ def ref(tmp_path_factory):
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "sim", "gapenc_ref.c")])
     L = C.CDLL(so)
     L.gapenc_ref.restype = C.c_int
-    L.gapenc_ref.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.gapenc_ref.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 
-    def encode(plane):
+    def encode(plane, depth=2):        # depth 2 = the default effort (clevel 5)
         out = np.zeros(N + 64, np.uint8)
-        n = L.gapenc_ref(plane.ctypes.data, N, out.ctypes.data)
+        n = L.gapenc_ref(plane.ctypes.data, N, out.ctypes.data, depth)
         return None if n < 0 else out[:n].copy()
     return encode
 
@@ -46,7 +46,7 @@ def edge_planes():
     out = [z.copy()]
     for pos in ([0], [N - 1], [0, N - 1], [1], [5], [6], [7], [N - 5], [N - 6], [N - 12], [N - 13], [2000], [63], [64], [65],
                 list(range(0, N, 7)), list(range(3, N, 64)), list(range(0, N, 2)), list(range(100, 140)), [10, 11, 12, 30, 31, 32, 50],
-                list(range(0, 1020 * 4, 4)), list(range(0, 1021 * 4, 4))):
+                list(range(0, 764 * 5, 5)), list(range(0, 765 * 5, 5))):
         a = z.copy()
         a[pos] = 1
         out.append(a)
@@ -118,6 +118,25 @@ def test_random_planes_match_the_reference(ctx, ref, scale, seed):
     assert n_ref >= 120
     if scale == 1.0:
         assert planes.size / total > 5.0          # the ratio the byte-wise encoder reaches on such planes is 5.12
+
+
+@pytest.mark.parametrize("clevel,depth", [(1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 24)])
+def test_effort_levels_match_the_reference(ctx, ref, clevel, depth):
+    """clevel -> candidates per one along the hash chain; every level byte-identical to the reference at that depth,
+    deeper levels no larger"""
+    rng = np.random.default_rng(77)
+    planes = bench_like(rng, 64)
+    ctx.set_clevel(clevel)
+    try:
+        got, total = run_planes(ctx, planes)
+    finally:
+        ctx.set_clevel(5)
+    for k, pl in enumerate(planes):
+        want = ref(pl, depth)
+        assert np.array_equal(got[k], want), f"clevel {clevel}: plane {k} differs from gapenc_ref(depth={depth})"
+    ratio = planes.size / total
+    lo = {0: 3.0, 1: 4.8, 2: 5.0, 4: 5.2, 8: 5.4, 24: 5.7}[depth]
+    assert ratio > lo, (clevel, ratio)
 
 
 def test_edge_planes(ctx, ref):

@@ -6,7 +6,9 @@
 // Input: a plane of n = 4096 bytes, all 0 or 1.  Walks the ONES q_0 < q_1 < ... (a virtual one at -1 in front and
 // one at n behind).  P[j+1] = q_j + 1.  For every one j:
 //   * context = bits q .. q+11, hashed into a 256-entry table of one indices; the table is updated one by one in
-//     stream order (on the GPU: one ds_wrxchg_rtn_b32 per 64 ones — the LDS serves equal addresses in lane order)
+//     stream order (on the GPU: one ds_wrxchg_rtn_b32 per 64 ones — the LDS serves equal addresses in lane order);
+//     what an insertion replaces is remembered (chain), so `depth` candidates can be tried per one: the table's entry,
+//     what that one replaced, ... — the candidate that saves most wins (depth 0: no hash matches, runs only)
 //   * candidate jc = previous one with that hash.  Forward length from the GAPS: while the gaps behind the two ones
 //     are equal (at most 8 of them) take gap + 1, then 1 + the smaller gap.  costR = what coding the covered ones
 //     as literals (+ offset-1 runs for gaps >= 7) would take; tailz = zeros left of the last covered one's gap
@@ -19,7 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#define N_MAXONES 1020
+#define N_MAXONES 764
 #define HLOG 8
 #define MINM 6
 #define BACK 8
@@ -46,8 +48,9 @@ static int put_seq(const uint8_t *in, uint8_t *out, int op, int anchor, int star
 }
 
 // returns the compressed size, or -1 if the plane is not handled by the bit-plane path (a byte > 1, too many ones)
-int gapenc_ref(const uint8_t *in, int n, uint8_t *out)
+int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
 {
+    static __thread int chain[4100];
     static __thread int P[4096 + 4];
     int m = 0;
     P[0] = 0;
@@ -66,36 +69,41 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out)
     for (int j = -1; j < m; ++j) {
         const int q = P[j + 1] - 1;
         int hv = 0, len = 0, nb = 0, c = 0;
-        if (j >= 0 && q + 12 <= n) {
+        if (depth > 0 && j >= 0 && q + 12 <= n) {
             uint32_t ctx = 0;
             for (int k = 0; k < 12; ++k) ctx |= (uint32_t)in[q + k] << k;
             const uint32_t idx = (ctx * 2654435761u) >> (32 - HLOG);
-            const int jc = (int)tab[idx] - 1;
+            int jc = (int)tab[idx] - 1;
             tab[idx] = (uint32_t)(j + 1);
-            if (jc >= 0) {
-                c = P[jc + 1] - 1;
-                int a = j, b = jc, pa = q + 1, pb = c + 1, costR = 0, tailz = 0;
+            chain[j] = jc;
+            int best_gain = -100000;
+            for (int dpt = 0; dpt < depth && jc >= 0; ++dpt, jc = chain[jc]) {
+                const int cc = P[jc + 1] - 1;
+                int clen = 0, cnb;
+                int a = j, b = jc, pa = q + 1, pb = cc + 1, costR = 0, tailz = 0;
                 for (int s = 0;; ++s) {
                     const int na = P[a + 2], nbn = P[b + 2];
                     const int ga = na - pa - 1, gb = nbn - pb - 1;
                     costR += 1 + (ga >= MINM + 1 ? 4 : ga);
                     if (ga != gb || a + 1 >= m || s >= STEPS) {
                         const int z = ga < gb ? ga : gb;
-                        len += 1 + z;
+                        clen += 1 + z;
                         tailz = ga - z;
                         break;
                     }
-                    len += 1 + ga;
+                    clen += 1 + ga;
                     ++a; ++b; pa = na; pb = nbn;
                 }
-                const int gq = q + 1 - P[j] - 1, gc = c + 1 - P[jc] - 1;
-                nb = gq < gc ? gq : gc;
-                if (nb > BACK) nb = BACK;
-                const int costH = 3 + (len + nb >= 19 ? 1 : 0) - nb + (tailz >= MINM ? 3 : tailz);
-                int end = q + len;
+                const int gq = q + 1 - P[j] - 1, gc = cc + 1 - P[jc] - 1;
+                cnb = gq < gc ? gq : gc;
+                if (cnb > BACK) cnb = BACK;
+                const int costH = 3 + (clen + cnb >= 19 ? 1 : 0) - cnb + (tailz >= MINM ? 3 : tailz);
+                int end = q + clen;
                 if (end > matchlimit) end = matchlimit;
-                hv = costH < costR && end - q >= 4 && end - (q - nb) >= MINM && q <= mflimit;
-                len = end - q;
+                const int gain = costR - costH;
+                if (gain > 0 && end - q >= 4 && end - (q - cnb) >= MINM && q <= mflimit && gain > best_gain) {
+                    best_gain = gain; hv = 1; len = end - q; nb = cnb; c = cc;
+                }
             }
         }
         const int e = hv ? q + len : q + 1;
