@@ -481,7 +481,7 @@ def main():
     # step, over the step time, over the HBM peak
     b_whole = text_bytes + g_bytes + g_bytes + comp_bytes
     step_s = dt_max / args.steps
-    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_blocks", "encode": "k_encode_tiles", "index": "k_index_newlines",
+    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_bitplanes", "encode": "k_encode_tiles", "index": "k_index_newlines",
                                        "frame": "k_frame_write"}.get(dom, dom),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
@@ -490,7 +490,8 @@ def main():
                            "definition": "SURVEY 8d: V (F + 6 S) + V' 2 S (1 + 1/r) over the step time over 8 TB/s"}}
     if dom == "lz4":
         # the contract's roofline is HBM or MFMA; this kernel is bound by neither
-        roof["limiter"] = "instruction issue: VALU and scalar unit ~90 % busy per PMC (profiles/*_pmc_lz4_sq.csv), HBM idle"
+        roof["limiter"] = ("vector-instruction issue and LDS round-trip latency: ~2.6 k vector + 1.3 k scalar + 0.3 k LDS "
+                           "instructions per 4 KiB plane at 8 waves per SIMD (profiles/r02_pmc_lz4_sq.txt); HBM mostly idle")
 
     out = {
         "metric": "variants/sec encode+compress, 3M-variant x 2.5k-sample VCF",

@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t bp_scan_max(uint32_t x, uint32_t lane)   // 
 }
 
 // 32 bits of the map starting at bit q (0 <= q < 4096 + 96)
-__device__ __forceinline__ uint32_t bp_bits(const volatile uint32_t *bm, uint32_t q)
+__device__ __forceinline__ uint32_t bp_bits(const uint32_t *bm, uint32_t q)
 {
     const uint32_t i = q >> 5;
     const uint32_t lo = bm[i], hi = bm[i + 1];
@@ -95,10 +95,11 @@ __device__ __forceinline__ uint32_t bp_bits(const volatile uint32_t *bm, uint32_
 
 __device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return x >= 15u ? (x - 15u) / 255u + 1u : 0u; }
 
-// one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off).  `out` is the
-// staging area in LDS or, for a window too large for it, the stream's slot in global memory (generic pointer).
-__device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t *out, uint32_t at, uint32_t anchor,
-                                           uint32_t start, uint32_t len, uint32_t off, bool on)
+// one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off).  OUT is a pointer
+// into the staging area (LDS: ds_write_b8) or, for a window too large for it, into the stream's slot in global memory.
+template <typename OUT>
+__device__ __forceinline__ void bp_put_seq(const uint32_t *bm, OUT out, uint32_t at, uint32_t anchor, uint32_t start, uint32_t len,
+                                           uint32_t off, bool on, uint32_t lane)
 {
     const uint32_t ll = on ? start - anchor : 0u, ml = len - 4u;
     const uint32_t llx = on ? bp_len_ext(ll) : 0u, mlx = on ? bp_len_ext(ml) : 0u;
@@ -111,13 +112,23 @@ __device__ __forceinline__ void bp_put_seq(const volatile uint32_t *bm, uint8_t 
         }
     }
     const uint32_t lit = at + 1u + llx;
-    // literals: lockstep over the longest run of the wave (typically 1-3 bytes); 32 bits of the map per refill
-    uint32_t b = 0;
-    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < ll) != 0ull; ++k) {
-        if (k < ll) {
-            if ((k & 31u) == 0u) b = bp_bits(bm, anchor + k);
-            out[lit + k] = (uint8_t)(b & 1u);
-            b >>= 1;
+    // literals.  Most runs are 1-3 bytes ("1", "1 0"): up to 6 go out as predicated byte stores of the owning lane.
+    // Longer runs (the literals of all the ones in between that code nothing pile up in front of the next sequence)
+    // are written by the whole wave, one run at a time — a lockstep per-lane loop would run max(ll) times for all.
+    if (__builtin_amdgcn_ballot_w64(ll != 0u) != 0ull) {
+        const uint32_t b = bp_bits(bm, anchor);
+        const bool small = ll <= 6u;
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; ++k)
+            if (small && k < ll) out[lit + k] = (uint8_t)((b >> k) & 1u);
+        unsigned long long big = __builtin_amdgcn_ballot_w64(ll > 6u);
+        while (big != 0ull) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1ull;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ll, l);
+            const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)anchor, l);
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)lit, l);
+            for (uint32_t k = lane; k < n; k += 64u) out[dst + k] = (uint8_t)(bp_bits(bm, src + k) & 1u);
         }
     }
     if (on) {
@@ -195,11 +206,17 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     __syncthreads();
 
     // ---- phase B: wave w codes plane w
+    // The lanes of the wave exchange data through S with no barrier in between: the LDS executes a wave's instructions in
+    // order.  What the COMPILER must not do is move a lane's read in front of another lane's earlier write; every such
+    // hand-over below is an access whose address it cannot tell apart from the lane's own writes, and BP_FENCE marks
+    // the phase boundaries for good measure.  (volatile pointers would also do — and turn every access into a
+    // serialised flat load with its own wait, which made this kernel 2x slower than it had to be.)
+#define BP_FENCE() asm volatile("" ::: "memory")
     BpLds<CHAIN> &S = lds[wave];
-    volatile uint32_t *bm = S.bm;
-    volatile uint16_t *P = S.P;
-    volatile uint16_t *wpre = S.wpre;
-    volatile uint32_t *flag = S.flag;
+    uint32_t *bm = S.bm;
+    uint16_t *P = S.P;
+    uint16_t *wpre = S.wpre;
+    uint32_t *flag = S.flag;
     const uint64_t sidx = (uint64_t)blockIdx.x * 2u + wave;
     uint8_t *out = scratch + sidx * slot_bytes;
 
@@ -215,6 +232,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         return;
     }
     wpre[lane] = (uint16_t)(incl - cnt);
+    BP_FENCE();
     {   // the list of ones
         uint32_t lo = wlo, hi = whi, at = incl - cnt + 1u;
         if (lane == 0) P[0] = 0;
@@ -233,6 +251,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         }
         if (lane < 4u) P[m + 1u + lane] = (uint16_t)(BP_N + 1);
     }
+    BP_FENCE();
 #pragma unroll
     for (int k = 0; k < (1 << BP_HLOG) / 64; ++k) S.tab[64 * k + lane] = 0u;
 
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             jc1 = atomicExch(&S.tab[idx], (uint32_t)(j + 1));
             if (CHAIN) S.chain[jj] = (uint16_t)jc1;   // what this one replaced: the next candidate down the chain
         }
+        BP_FENCE();
         // ---- candidates: forward length from the gaps; DEPTH of them along the chain, the one that saves most wins
         const uint32_t gq = q1 - qp1 - 1u;
         uint32_t len = 0, nb = 0, c1 = 0;
@@ -364,10 +384,12 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             const uint32_t p0 = jump;
             flag[lane] = lane == e0 ? 1u : 0u;
             if (lane == 0) flag[64] = 0u;
+            BP_FENCE();
             bool reach = lane == e0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 if (reach) flag[jump] = 1u;
+                BP_FENCE();
                 reach = flag[lane] != 0u;
                 const uint32_t j2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jump & 63u) << 2), (int)jump);
                 jump = jump < 64u ? j2 : 64u;
@@ -399,48 +421,60 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
         // the window's bytes go to the staging area; what is staged leaves in coalesced dwords when the next window
         // would not fit (a window larger than the whole area is written to global memory directly)
+        BP_FENCE();
         if (sop + total > BP_STAGE) {
             bp_flush(S.stage, out + gop, sop, lane);
             gop += sop;
             sop = 0;
         }
-        const bool direct = total > BP_STAGE;
-        uint8_t *dstp = direct ? out + gop : static_cast<uint8_t *>(S.stage) + sop;
         const uint32_t at = sincl - (szM + szT);
-        bp_put_seq(bm, dstp, at, pe, ms, lenM, q1 - c1, onM);
-        bp_put_seq(bm, dstp, at + szM, pe2, rs, lenT, 1u, onT);
-        if (direct) gop += total;
-        else sop += total;
+        if (total > BP_STAGE) {   // (wave-uniform, rare: a window with hundreds of literals)
+            bp_put_seq(bm, out + gop, at, pe, ms, lenM, q1 - c1, onM, lane);
+            bp_put_seq(bm, out + gop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+            gop += total;
+        } else {
+            bp_put_seq(bm, S.stage + sop, at, pe, ms, lenM, q1 - c1, onM, lane);
+            bp_put_seq(bm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+            sop += total;
+        }
         const uint32_t fmax = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
         prev_end = fmax > prev_end ? fmax : prev_end;
     }
     // ---- last literals
     {
         const uint32_t ll = BP_N - prev_end, llx = bp_len_ext(ll);
+        BP_FENCE();
         if (sop + 1u + llx + ll > BP_STAGE) {
             bp_flush(S.stage, out + gop, sop, lane);
             gop += sop;
             sop = 0;
         }
         const bool direct = 1u + llx + ll > BP_STAGE;
-        uint8_t *dstp = direct ? out + gop : static_cast<uint8_t *>(S.stage) + sop;
-        if (lane == 0) {
-            dstp[0] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
-            uint32_t r = ll - 15u;
-            for (uint32_t k = 0; k < llx; ++k) {
-                dstp[1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
-                r -= 255u;
+        auto tail = [&](auto dstp) {
+            if (lane == 0) {
+                dstp[0] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
+                uint32_t r = ll - 15u;
+                for (uint32_t k = 0; k < llx; ++k) {
+                    dstp[1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
+                    r -= 255u;
+                }
             }
+            for (uint32_t k = lane; k < ll; k += 64u) dstp[1u + llx + k] = (uint8_t)(bp_bits(bm, prev_end + k) & 1u);
+        };
+        if (direct) {
+            tail(out + gop);
+            gop += 1u + llx + ll;
+        } else {
+            tail(S.stage + sop);
+            sop += 1u + llx + ll;
         }
-        for (uint32_t k = lane; k < ll; k += 64u) dstp[1u + llx + k] = (uint8_t)(bp_bits(bm, prev_end + k) & 1u);
-        if (direct) gop += 1u + llx + ll;
-        else sop += 1u + llx + ll;
     }
     uint32_t op = gop + sop;
     if (op >= BP_N) {   // incompressible: Blosc stores the (shuffled) stream verbatim
         for (uint32_t k = lane; k < BP_N; k += 64u) out[k] = (uint8_t)(bp_bits(bm, k) & 1u);
         op = BP_N;
     } else {
+        BP_FENCE();
         bp_flush(S.stage, out + gop, sop, lane);
     }
     if (lane == 0) csize[sidx] = op;
