@@ -13,7 +13,8 @@ LIB = os.path.join(HERE, "libhhgt.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 SOURCES = ["scan.hip", "index.hip", "encode.hip", "lz4.hip", "lz4bits.hip", "frame.hip", "decode.hip", "inflate.hip", "synth.hip",
            "reader.hip", "ingest.hip", "onehot.hip", "api.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# -mssse3: host side only (pshufb in csrc/fast_inflate.h; every x86-64 host of an MI355X has it)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mssse3"]
 
 
 def _hipcc():

@@ -55,6 +55,11 @@ void hhgt_reader_trim_pool(void);
  * reader checks every BGZF member with), the 16-byte table form elsewhere. */
 uint32_t hhgt_crc32(const void *data, uint64_t n);
 
+/* Raw DEFLATE (RFC 1951) of one BGZF member: 0 iff the stream is complete and inflates to exactly out_len bytes.  The
+ * decoder the reader's workers use (csrc/fast_inflate.h) before falling back to zlib; never touches memory outside
+ * the two buffers. */
+int hhgt_fast_inflate(const void *in, uint64_t in_len, void *out, uint64_t out_len);
+
 /* hipMemcpyAsync(d_dst, host_ptr, nbytes, HostToDevice, stream) from the reader's pinned block */
 int hhgt_reader_copy_async(hhgt_reader *r, const void *host_ptr, uint64_t nbytes, void *d_dst, void *stream);
 
