@@ -9,9 +9,12 @@
 // at 6 %.  This kernel turns the plane into a 4096-bit map and works on the LIST OF ONES (~260 per plane):
 //
 //   * one lane per one, 64 ones per window (4-5 windows per plane instead of 52-64);
-//   * hash table keyed on the 12 bits at the one, updated by ONE ds_wrxchg_rtn_b32 per window: the LDS serves lanes
-//     that hit the same address in ascending lane order (tools/micro/lds_xchg_order.hip, checked by a test), so every
-//     lane gets the most recent earlier one with its key — exact sequential hash-table semantics, 64 insertions at once;
+//   * candidate table keyed on the GAP behind the one (distance to the next one, clipped to 40: 64 entries, no hash),
+//     updated by ONE ds_wrxchg_rtn_b32 per window: the LDS serves lanes that hit the same address in ascending lane
+//     order (tools/micro/lds_xchg_order.hip, checked by a test), so every lane gets the most recent earlier one with its
+//     key — exact sequential table semantics, 64 insertions at once.  (The first version keyed the table on the 12 bits
+//     at the one, LZ4's habit; on these planes that context is "a one and eleven zeros" nearly everywhere.  An equal
+//     first gap is what a match of ones needs to get past its first step: ratio 5.31 -> 5.86 at two candidates.)
 //   * match lengths come from comparing GAPS between ones (a few LDS reads per one), not bytes: equal gaps, then one
 //     plus the shorter of the first unequal pair; matches are pulled back over up to 8 literal zeros in front;
 //   * every one decides locally between "match" and "literal" by cost (3 bytes per sequence against the literals and
@@ -29,7 +32,8 @@
 #define BP_N 4096
 #define BP_MAXONES 764
 #define BP_STAGE 1024
-#define BP_HLOG 8
+#define BP_HLOG 6
+#define BP_GAPCLIP 40
 #define BP_MINM 6
 #define BP_BACK 8
 #define BP_STEPS 8
@@ -38,7 +42,7 @@
 
 template <bool CHAIN> struct BpLds {
     uint32_t bm[132];                // bit map of the plane: 128 dwords + zero padding
-    uint32_t tab[1 << BP_HLOG];      // context hash -> one index + 1
+    uint32_t tab[1 << BP_HLOG];      // min(gap behind the one + 1, BP_GAPCLIP) -> one index + 1
     uint32_t flag[68];               // pointer-doubling marks of a window
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
     uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
@@ -264,12 +268,12 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         const uint32_t q1 = P[jj], qn1 = P[jj + 1u];
         const uint32_t qp1 = jj ? P[jj - 1u] : 0u;
         const int q = (int)q1 - 1;
-        // ---- hash table: context of 12 bits at the one; exact recency through the LDS's lane order
+        // ---- candidate table: keyed on the gap behind the one; exact recency through the LDS's lane order
         const bool can = DEPTH > 0 && valid && j >= 0 && q + 12 <= BP_N;
         uint32_t jc1 = 0;
         if (can) {
-            const uint32_t ctx = bp_bits(bm, (uint32_t)q) & 0xFFFu;
-            const uint32_t idx = (ctx * 2654435761u) >> (32 - BP_HLOG);
+            const uint32_t g1 = qn1 - q1;
+            const uint32_t idx = g1 < BP_GAPCLIP ? g1 : BP_GAPCLIP;
             jc1 = atomicExch(&S.tab[idx], (uint32_t)(j + 1));
             if (CHAIN) S.chain[jj] = (uint16_t)jc1;   // what this one replaced: the next candidate down the chain
         }
@@ -497,7 +501,7 @@ int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scr
     else if (depth == 2) BP_LAUNCH(2);
     else if (depth <= 4) BP_LAUNCH(4);
     else if (depth <= 8) BP_LAUNCH(8);
-    else BP_LAUNCH(24);
+    else BP_LAUNCH(16);
 #undef BP_LAUNCH
     HIP_TRY(hipGetLastError());
     return HHGT_OK;

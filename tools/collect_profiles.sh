@@ -4,7 +4,8 @@
 #   1. the default bench line                                  (bench_line.json)
 #   2. rocprofv3 --kernel-trace --stats on the same command    (<tag>_kernel_stats.csv, bench_line_under_rocprof.json)
 #   3. FETCH_SIZE and WRITE_SIZE, separate --pmc passes, small workload (f_/w_counter_collection.csv)
-#   4. SQ instruction-mix counters of the LZ4 kernel           (sq_counter_collection.csv)
+#   4. SQ instruction-mix counters of the LZ4 kernels          (sq_counter_collection.csv)
+#   5. the end-to-end lines of tools/e2e_bench.py               (e2e_*.json)
 # tools/summarize_profiles.py turns 3 into the per-variant byte counts DESIGN.md quotes.
 set -e
 tag=${1:-x}
@@ -16,11 +17,17 @@ cd $R
 timeout -k 10 400 python3 bench.py > $O/bench.log 2>&1
 grep "^{" $O/bench.log > $O/bench_line.json
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O -o $tag --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/rocprof_stdout.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O -o $tag --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-legs --no-check > $O/rocprof_stdout.log 2>&1
 grep "^{" $O/rocprof_stdout.log > $O/bench_line_under_rocprof.json
-B="python3 $R/bench.py --variants 300000 --steps 1 --warmup 0 --no-cpu-baseline --no-overlap"
+B="python3 $R/bench.py --variants 300000 --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-legs --no-check"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O -o f --output-format csv -- $B > $O/out_f.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O -o w --output-format csv -- $B > $O/out_w.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU \
   --kernel-include-regex k_lz4 -d $O -o sq --output-format csv -- $B > $O/out_sq.log 2>&1
+cd $R
+for k in "--kind bgzf" "--kind bgzf --device-inflate" "--kind plain" "--kind memory"; do
+  n=$(echo $k | tr -d ' -' )
+  timeout -k 10 300 python3 tools/e2e_bench.py $k --chroms 1,2,3,4 --repeat 3 > $O/e2e_$n.log 2>&1
+  grep "^{" $O/e2e_$n.log > $O/e2e_$n.json
+done
 ls $O

@@ -5,7 +5,7 @@
 //
 // Input: a plane of n = 4096 bytes, all 0 or 1.  Walks the ONES q_0 < q_1 < ... (a virtual one at -1 in front and
 // one at n behind).  P[j+1] = q_j + 1.  For every one j:
-//   * context = bits q .. q+11, hashed into a 256-entry table of one indices; the table is updated one by one in
+//   * key = min(distance to the next one, 40), a 64-entry table of one indices; the table is updated one by one in
 //     stream order (on the GPU: one ds_wrxchg_rtn_b32 per 64 ones — the LDS serves equal addresses in lane order);
 //     what an insertion replaces is remembered (chain), so `depth` candidates can be tried per one: the table's entry,
 //     what that one replaced, ... — the candidate that saves most wins (depth 0: no hash matches, runs only)
@@ -22,7 +22,8 @@
 #include <string.h>
 
 #define N_MAXONES 764
-#define HLOG 8
+#define HLOG 6
+#define GAPCLIP 40
 #define MINM 6
 #define BACK 8
 #define STEPS 8
@@ -70,9 +71,8 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
         const int q = P[j + 1] - 1;
         int hv = 0, len = 0, nb = 0, c = 0;
         if (depth > 0 && j >= 0 && q + 12 <= n) {
-            uint32_t ctx = 0;
-            for (int k = 0; k < 12; ++k) ctx |= (uint32_t)in[q + k] << k;
-            const uint32_t idx = (ctx * 2654435761u) >> (32 - HLOG);
+            const uint32_t g1 = (uint32_t)(P[j + 2] - P[j + 1]);
+            const uint32_t idx = g1 < GAPCLIP ? g1 : GAPCLIP;
             int jc = (int)tab[idx] - 1;
             tab[idx] = (uint32_t)(j + 1);
             chain[j] = jc;

@@ -48,22 +48,33 @@ out = {
                    "(MI355X_MICROARCH.md §HBM): fetch bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 is exact",
     "variants_per_pass": VARIANTS,
 }
-for name, kern in (("lz4", "k_lz4_blocks"), ("encode", "k_encode_tiles"), ("index", "k_index_newlines"),
-                   ("frame", "k_frame_write"), ("fixed", "k_parse_fixed")):
-    if kern not in f:
+# the "lz4" stage is two launches per shard: the bit-plane coder, then the byte-wise coder over the streams it marked
+for name, kerns in (("lz4", ("k_lz4_bitplanes", "k_lz4_blocks")), ("encode", ("k_encode_tiles",)), ("index", ("k_index_newlines",)),
+                    ("frame", ("k_frame_write",)), ("fixed", ("k_parse_fixed",))):
+    kerns = [k for k in kerns if k in f]
+    if not kerns:
         continue
-    fb = f[kern] * 1024 * 2 / (VARIANTS * PASSES)
-    wb = w[kern] * 1024 / (VARIANTS * PASSES)
-    out[name] = {"kernel": kern, "fetch_bytes_per_variant": fb, "write_bytes_per_variant": wb,
-                 "hbm_bytes_per_variant": fb + wb, "launches": nf[kern]}
+    fb = sum(f[k] for k in kerns) * 1024 * 2 / (VARIANTS * PASSES)
+    wb = sum(w[k] for k in kerns) * 1024 / (VARIANTS * PASSES)
+    out[name] = {"kernel": "+".join(kerns), "fetch_bytes_per_variant": fb, "write_bytes_per_variant": wb,
+                 "hbm_bytes_per_variant": fb + wb, "launches": {k: nf[k] for k in kerns}}
 json.dump(out, open(f"profiles/{prefix}_pmc_summary.json", "w"), indent=1)
 shutil.copy(find("counter_collection.csv", "sq_"), f"profiles/{prefix}_pmc_lz4_sq.csv")
-acc, n = collections.defaultdict(float), collections.Counter()
-grid = 0
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+grid = collections.Counter()
 for r in csv.DictReader(open(f"profiles/{prefix}_pmc_lz4_sq.csv")):
-    acc[r["Counter_Name"]] += float(r["Counter_Value"])
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES":
-        grid += int(r["Grid_Size"])
-streams = grid / 64
-print("lz4 per 4 KiB stream:", {k: round(v / streams, 1) for k, v in sorted(acc.items())})
+        grid[k] += int(r["Grid_Size"])
+# one 4 KiB plane stream per wave in k_lz4_bitplanes (128 lanes = one 8 KiB block = two planes)
+lines = []
+for k in acc:
+    waves = acc[k].get("SQ_WAVES", 0) or 1
+    lines.append(f"{k}: per wave " + json.dumps({c: round(v / waves, 1) for c, v in sorted(acc[k].items())}))
+open(f"profiles/{prefix}_pmc_lz4_sq.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+for f_ in os.listdir(src):
+    if f_.startswith("e2e_") and f_.endswith(".json") and os.path.getsize(os.path.join(src, f_)):
+        shutil.copy(os.path.join(src, f_), f"profiles/{prefix}_{f_}")
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
