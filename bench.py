@@ -368,7 +368,7 @@ def ingest_legs(ctx, shards, S, chroms, fmt):
             tb, tf, framed = run([(p, sh) for p, sh in zip(files, pick)], devinf)
             e2e[name] = {"value": V / tb, "unit": "variants/s", "text_GBps": text_bytes / tb / 1e9, "seconds": tb,
                          "first_pass_seconds": tf, "file_GBps": file_bytes / tb / 1e9,
-                         "inflater": "hhgt_reader: zlib inflate + PCLMUL CRC-32 on the granted host CPUs -> pinned ring -> hipMemcpyAsync"
+                         "inflater": "hhgt_reader: own DEFLATE decoder (csrc/fast_inflate.h, zlib as fallback) + PCLMUL CRC-32 on the granted host CPUs -> pinned ring -> hipMemcpyAsync"
                          if not devinf else "k_inflate_members + k_crc32_members on the device (compressed members cross PCIe)"}
         return host_fed, e2e
     finally:
@@ -490,8 +490,10 @@ def main():
                            "definition": "SURVEY 8d: V (F + 6 S) + V' 2 S (1 + 1/r) over the step time over 8 TB/s"}}
     if dom == "lz4":
         # the contract's roofline is HBM or MFMA; this kernel is bound by neither
-        roof["limiter"] = ("vector-instruction issue and LDS round-trip latency: ~2.6 k vector + 1.3 k scalar + 0.3 k LDS "
-                           "instructions per 4 KiB plane at 8 waves per SIMD (profiles/r02_pmc_lz4_sq.txt); HBM mostly idle")
+        sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_lz4_sq.txt")))
+        roof["limiter"] = ("vector-instruction issue and LDS round trips: ~2.1 k vector + 1.0 k scalar + 0.24 k LDS instructions "
+                           "per 4 KiB plane at 7-8 waves per SIMD (" + (os.path.basename(sq[-1]) if sq else "profiles/") +
+                           ", SQ counters from a separate --pmc pass); HBM at a sixth of its peak under this kernel")
 
     out = {
         "metric": "variants/sec encode+compress, 3M-variant x 2.5k-sample VCF",
