@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true", help="skip the host-fed / end-to-end legs")
     ap.add_argument("--legs-chroms", default="1,2,3,4", help="shards the host-fed / end-to-end legs run on")
     ap.add_argument("--no-check", action="store_true", help="skip the correctness gate")
+    ap.add_argument("--lz4-priority", action="store_true", help="development: the compress stream gets the high priority")
+    ap.add_argument("--cu-split", default="", help="development: 'E,C' = the encode stream may use the first E CUs of the mask "
+                                                   "order, the compress stream the last C (hipExtStreamCreateWithCUMask)")
     return ap.parse_args()
 
 
@@ -123,6 +126,23 @@ def build_shards(ctx, args, rank, world):
         sh.max_lines = V + 64
         shards.append(sh)
     return shards
+
+
+def masked_streams(n_enc, n_cmp, n_cu=256):
+    """two HIP streams restricted to disjoint (or overlapping) CU sets, wrapped for torch"""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    out = []
+    for lo, hi in ((0, n_enc), (n_cu - n_cmp, n_cu)):
+        words = (C.c_uint32 * (n_cu // 32))()
+        for i in range(lo, hi):
+            words[i // 32] |= 1 << (i % 32)
+        st = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), n_cu // 32, words)
+        assert rc == 0, rc
+        out.append(torch.cuda.ExternalStream(st.value))
+    return tuple(out)
 
 
 def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
@@ -417,7 +437,14 @@ def main():
 
     # the HBM-bound index/encode kernels go on a high-priority stream so that the many small LZ4 workgroups
     # of the previous shard do not starve them of LDS
-    streams = None if args.no_overlap else (torch.cuda.Stream(priority=-1), torch.cuda.Stream())
+    if args.no_overlap:
+        streams = None
+    elif args.cu_split:
+        streams = masked_streams(*[int(x) for x in args.cu_split.split(",")])
+    elif args.lz4_priority:
+        streams = (torch.cuda.Stream(), torch.cuda.Stream(priority=-1))
+    else:
+        streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream())
     for _ in range(args.warmup):
         one_step(ctx, shards, S, args.blocksize, streams, args.lookahead)
     barrier()

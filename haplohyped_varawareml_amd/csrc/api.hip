@@ -341,15 +341,16 @@ static int encode_check_args(hhgt_ctx *c, const void *d_text, uint64_t nbytes, c
     return parse_region_host(region, rf);
 }
 
-// stage 1: newline index of the block -> prefix[n_regions] holds the line count (device)
-static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, DevCounters *cnt,
-                              hipStream_t st)
+// stage 1: newline index of the block -> prefix[n_regions] holds the line count (device).  min_line: a record with S
+// sample columns cannot be shorter than 9 fixed columns and S fields of one byte and a separator each (0: unknown)
+static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, uint32_t min_line,
+                              DevCounters *cnt, hipStream_t st)
 {
     TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
     TRY(c->counts.ensure((size_t)n_regions * 4));
     TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
     TRY(c->scan_tmp.ensure(scan_tmp_elems(n_regions) * 4));
-    TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, cnt, st));
+    TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, min_line, cnt, st));
     TRY(launch_scan_exclusive_u32(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), n_regions,
                                   c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
     return HHGT_OK;
@@ -480,7 +481,7 @@ extern "C" int hhgt_encode_text_async(hhgt_ctx *c, const void *d_text, uint64_t 
     if (nbytes) {
         {
             StageTimer t(c, st, HHGT_STAGE_INDEX);
-            TRY(encode_stage_index(c, text, nbytes, n_regions, cnt, st));
+            TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, cnt, st));
             t.stop();
         }
         TRY(encode_stage_rest(c, text, nbytes, n_regions, max_lines, rf, L, d_cursor, d_G, d_start, d_stop, d_ref, d_alt, cnt, st));
@@ -520,7 +521,7 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
         // the synchronous form sizes everything by the exact line count: it is read back once (any input, however
         // short its lines, fits), where the asynchronous form takes the caller's bound
         StageTimer t(c, st, HHGT_STAGE_INDEX);
-        TRY(encode_stage_index(c, text, nbytes, n_regions, cnt, st));
+        TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, cnt, st));
         c->h_counters->n_lines = 0;
         c->h_counters->err_density = 0;
         HIP_TRY(hipMemcpyAsync(&c->h_counters->n_lines, c->prefix.as<uint32_t>() + n_regions, 4,

@@ -135,7 +135,7 @@ size_t scan_tmp_elems(uint64_t n);
 
 // index.hip
 int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
-                          uint32_t n_regions, DevCounters *d_cnt, hipStream_t st);
+                          uint32_t n_regions, uint32_t min_line, DevCounters *d_cnt, hipStream_t st);
 // Everything after the newline index is sized by a host-side BOUND on the line count (max_lines) and reads the
 // actual count (d_nlines = prefix[n_regions]) and the append position (d_cursor) from device memory, so the chain
 // can be queued without a host round trip (hhgt_encode_text_async).

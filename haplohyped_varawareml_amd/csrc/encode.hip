@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         const uint64_t vin = v - vcol * lay.Vc;
         if (lay.ring) vcol %= lay.ring;
         const uint32_t rs = soff - 1u;  // the 9th tab: every sample field is preceded by a tab in [rs, lend)
-        uint32_t tabs_before = 0;
+        uint32_t tabs_before = 0, nl_inside = 0;
         for (uint32_t base = rs; base < lend; base += 1024u) {
             const uint32_t b0 = base + 16u * lane;
             uint32_t m = 0;
@@ -269,6 +269,8 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                     const uint32_t t = wv[q] ^ 0x09090909u;
                     const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
                     m |= ((((z >> 7) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+                    const uint32_t tn = wv[q] ^ 0x0A0A0A0Au;
+                    nl_inside |= (tn - 0x01010101u) & ~tn & 0x80808080u;   // a newline in front of the line's own
                 }
             } else if (b0 < lend) {
                 for (uint32_t j = 0; j < 16u; ++j) {
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                         const uint8_t ch = text[p];
                         buf[16u * lane + j] = ch;
                         if (ch == '\t') m |= 1u << j;
+                        if (ch == '\n') nl_inside = 1u;
                     }
                 }
             }
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
             }
             tabs_before += __shfl(inc, 63, 64);
         }
-        if (tabs_before < S && lane == 0) ++malformed;  // fewer sample columns than the header declares
+        // fewer sample columns than the header declares; or a line end inside the line: a line shorter than any record
+        // with S samples can be (its newline lay in the part the hopping index does not look at, index.hip)
+        const bool broken = __builtin_amdgcn_ballot_w64(nl_inside != 0u) != 0ull;
+        if ((tabs_before < S || broken) && lane == 0) ++malformed;
     }
     // one atomic per wave
 #pragma unroll
@@ -409,6 +415,8 @@ int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_sof
 {
     if (n_lines_bound == 0 || lay.S == 0) return HHGT_OK;
     static const int tv = getenv("HHGT_TILE_V") ? atoi(getenv("HHGT_TILE_V")) : 64;
+    // development: extra (unused) dynamic LDS per workgroup = fewer workgroups per CU (co-residency experiments)
+    static const int enc_lds_pad = getenv("HHGT_ENC_LDS_PAD") ? atoi(getenv("HHGT_ENC_LDS_PAD")) : 0;
     uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
     if (tv == 128) {
         // the append position is only known on the device: one tile more than the lines need covers any phase
@@ -417,7 +425,7 @@ int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_sof
                            k_meta, d_cursor, lay, d_G, redo_list, redo_flag, d_cnt);
     } else {
         uint64_t tiles_v = (63 + (uint64_t)n_lines_bound + 63) / 64;
-        hipLaunchKernelGGL(k_encode_tiles<64>, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff,
+        hipLaunchKernelGGL(k_encode_tiles<64>, dim3((uint32_t)tiles_v, tiles_s), dim3(256), enc_lds_pad, st, d_text, n, k_soff,
                            k_meta, d_cursor, lay, d_G, redo_list, redo_flag, d_cnt);
     }
     HIP_TRY(hipGetLastError());

@@ -90,6 +90,125 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
     if (lane == 0) counts[r] = wcount < INDEX_CAP ? wcount : INDEX_CAP;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_index_hop<U>: the same index for text whose lines cannot be shorter than `skip` bytes — a record with S sample
+// columns has at least 2 S + 17 bytes in front of its newline, so behind every line start that many bytes need not be
+// looked at.  For the 1000G shape (lines of 4 S + 58 bytes) that is half of the text: the pass reads ~5 KB per variant
+// where k_index_newlines reads 10 KB.  A wave owns HOP_K consecutive regions (128 KiB) and walks them line by line:
+// from `pos` it loads U KiB (16 B per lane, all loads in flight together), takes the first newline, appends it to the
+// slot list of the region it lies in (same slots / counts layout as k_index_newlines: everything downstream is
+// unchanged), looks at the first byte of the next line ('#' header lines and empty lines are short: no skip behind
+// them) and hops.  The first newline of a wave's range is found by plain scanning, so ranges need no hand-over.
+// A line that IS shorter than the bound (fewer sample columns than the header declares) is malformed either way; when
+// its newline falls into a hop it merges with the next line, and the general encoder reports the newline it then
+// finds inside the sample columns (encode.hip) — the same error, one record later.
+template <int U, uint32_t HOP_K>
+__global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ slots,
+                                                   uint32_t *__restrict__ counts, uint32_t n_regions, uint32_t skip,
+                                                   DevCounters *cnt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    const uint32_t r_first = w * HOP_K;
+    if (r_first >= n_regions) return;
+    const uint32_t r_cnt = n_regions - r_first < HOP_K ? n_regions - r_first : HOP_K;
+    const bool virt = n > 0 && text[n - 1] != '\n';   // a text that does not end in '\n' gets a virtual newline at n
+    const uint64_t beg = (uint64_t)r_first * INDEX_REGION;
+    uint64_t endw = beg + (uint64_t)r_cnt * INDEX_REGION;   // positions [beg, endw) are this wave's; position n counts
+    if (endw > n + 1) endw = n + 1;
+    const uint64_t last_term = virt ? n : n - 1;
+    uint32_t cntv = 0;        // lane i: newlines found in region r_first + i
+    bool overflow = false;
+    uint64_t pos = beg;
+    while (pos < endw) {
+        const uint64_t a0 = pos & ~15ull;
+        uint32_t any[U];
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t g0 = a0 + (uint64_t)u * 1024u + lane * 16u;
+            uint32_t f = 0;
+            v[u] = u32x4_t{0u, 0u, 0u, 0u};
+            if (g0 + 16 <= n) {
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(text + g0));   // streamed once
+                const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t t = d[q] ^ 0x0A0A0A0Au;
+                    f |= (t - 0x01010101u) & ~t & 0x80808080u;   // non-zero iff one of the four bytes is '\n'
+                }
+            } else if (g0 <= n) {
+                // the last bytes of the text: assembled byte by byte, position n holds the virtual newline
+                uint32_t d[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t g = g0 + j;
+                    uint32_t ch = 0x20u;
+                    if (g < n) ch = text[g];
+                    else if (g == n && virt) ch = 0x0Au;
+                    d[j >> 2] = (d[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | (ch << (8 * (j & 3)));
+                    if (ch == 0x0Au) f = 1u;
+                }
+                v[u] = u32x4_t{d[0], d[1], d[2], d[3]};
+            }
+            // bytes in front of pos are not part of the search
+            if (g0 + 16 <= pos) f = 0;
+            any[u] = f;
+        }
+        bool found = false, nb_have = false;
+        uint32_t nb_reg = 0;
+        uint64_t p = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (found) continue;
+            unsigned long long b = __builtin_amdgcn_ballot_w64(any[u] != 0u);
+            while (b != 0ull && !found) {
+                // the exact mask of the first flagged lane (its flag may stem from bytes in front of pos only)
+                const int l = __builtin_ctzll(b);
+                b &= b - 1ull;
+                const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)v[u].x, l), x1 = (uint32_t)__builtin_amdgcn_readlane((int)v[u].y, l);
+                const uint32_t x2 = (uint32_t)__builtin_amdgcn_readlane((int)v[u].z, l), x3 = (uint32_t)__builtin_amdgcn_readlane((int)v[u].w, l);
+                uint32_t m = nl_mask4(x0) | (nl_mask4(x1) << 4) | (nl_mask4(x2) << 8) | (nl_mask4(x3) << 12);
+                const uint64_t g0 = a0 + (uint64_t)u * 1024u + (uint64_t)l * 16u;
+                if (g0 < pos) m &= ~((1u << (uint32_t)(pos - g0)) - 1u);
+                if (m) {
+                    found = true;
+                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                    p = g0 + j;
+                    if (j < 15u && g0 + 16 <= n) {
+                        const uint32_t k = j + 1u, dw = k >> 2;
+                        const uint32_t xd = dw == 0u ? x0 : (dw == 1u ? x1 : (dw == 2u ? x2 : x3));
+                        nb_reg = (xd >> (8u * (k & 3u))) & 0xFFu;
+                        nb_have = true;
+                    }
+                }
+            }
+        }
+        if (!found) {
+            pos = a0 + (uint64_t)U * 1024u;
+            continue;
+        }
+        if (p >= endw) break;
+        {
+            const uint32_t rr = (uint32_t)(p / INDEX_REGION), local = rr - r_first;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)local);
+            if (c < INDEX_CAP) {
+                if (lane == 0) slots[(size_t)rr * INDEX_CAP + c] = (uint32_t)p;
+            } else
+                overflow = true;
+            cntv += lane == local ? 1u : 0u;
+        }
+        uint32_t nb = 0x0Au;
+        if (nb_have) nb = nb_reg;                 // the byte behind the newline came with the same 16 bytes (15 of 16 cases)
+        else if (p + 1 < n) nb = text[p + 1];
+        pos = p + 1 + ((nb == '#' || nb == 0x0Au) ? 0u : skip);
+        // the terminator of the text's last line is always looked at: a file cut off in mid-line ends in a line shorter
+        // than the bound, which has to reach the parser (and be reported), not vanish in a hop
+        if (pos > last_term) pos = p + 1 > last_term ? p + 1 : last_term;
+    }
+    if (overflow && lane == 0) atomicAdd(&cnt->err_density, 1ull);
+    if (lane < r_cnt) counts[r_first + lane] = cntv < INDEX_CAP ? cntv : INDEX_CAP;
+}
+
 // one thread per region: copy its slot entries to their final place
 __global__ __launch_bounds__(256) void k_compact_newlines(const uint32_t *__restrict__ slots,
                                                           const uint32_t *__restrict__ counts,
@@ -350,8 +469,27 @@ __global__ __launch_bounds__(256) void k_compact_kept(
 
 // ---------------------------------------------------------------------------------------------
 int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
-                          uint32_t n_regions, DevCounters *d_cnt, hipStream_t st)
+                          uint32_t n_regions, uint32_t min_line, DevCounters *d_cnt, hipStream_t st)
 {
+    // min_line: no line of this text can be shorter (0 = unknown).  Long lines: the hopping index reads the text behind
+    // the bound only; HHGT_INDEX_HOP=0 keeps the plain scan.
+    static const int hop = getenv("HHGT_INDEX_HOP") ? atoi(getenv("HHGT_INDEX_HOP")) : 1;
+    if (hop && min_line >= 1536u) {
+        const uint32_t skip = min_line - 16u;      // margin: the loads start at the 16-byte line in front of the target
+        static const int hop_k = getenv("HHGT_INDEX_HOP_K") ? atoi(getenv("HHGT_INDEX_HOP_K")) : 8;   // development
+#define HOP_LAUNCH(U, K)                                                                                                   \
+    hipLaunchKernelGGL((k_index_hop<U, K>), dim3(((n_regions + K - 1) / K + 3) / 4), dim3(256), 0, st, d_text, n, d_slots, d_counts, \
+                       n_regions, skip, d_cnt)
+        if (min_line >= 4096u) {
+            if (hop_k == 2) HOP_LAUNCH(5, 2u);
+            else if (hop_k == 4) HOP_LAUNCH(5, 4u);
+            else HOP_LAUNCH(5, 8u);
+        } else
+            HOP_LAUNCH(3, 4u);
+#undef HOP_LAUNCH
+        HIP_TRY(hipGetLastError());
+        return HHGT_OK;
+    }
     hipLaunchKernelGGL(k_index_newlines, dim3((n_regions + 3) / 4), dim3(256), 0, st, d_text, n, d_slots,
                        d_counts, n_regions, d_cnt);
     HIP_TRY(hipGetLastError());

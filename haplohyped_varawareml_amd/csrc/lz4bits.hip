@@ -37,6 +37,11 @@
 #define BP_MINM 6
 #define BP_BACK 8
 #define BP_STEPS 8
+#ifdef BP_MARKS   // development: section markers in the ISA listing (hipcc -S -DBP_MARKS), tools/isa_sections.py counts per section
+#define BP_MARK(name) asm volatile("; ==MARK " name)
+#else
+#define BP_MARK(name)
+#endif
 #define BP_MFLIMIT (BP_N - 12)
 #define BP_MATCHLIMIT (BP_N - 5)
 
@@ -207,7 +212,16 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
         if (threadIdx.x == 0) queued = 0u;
     }
+    BP_MARK("A_done");
     __syncthreads();
+#ifndef BP_SKIP
+#define BP_SKIP 0   // development: 1 no emission, 2 no layout either, 3 no selection, 4 no window loop, 5 phase A only (invalid output; timing only)
+#endif
+    uint32_t sink = 0;
+    if (BP_SKIP >= 5) {
+        if (lane == 0) csize[(uint64_t)blockIdx.x * 2u + wave] = lds[wave].bm[5] & 1u;
+        return;
+    }
 
     // ---- phase B: wave w codes plane w
     // The lanes of the wave exchange data through S with no barrier in between: the LDS executes a wave's instructions in
@@ -235,6 +249,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         }
         return;
     }
+    BP_MARK("scan_done");
     wpre[lane] = (uint16_t)(incl - cnt);
     BP_FENCE();
     {   // the list of ones
@@ -259,9 +274,15 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
 #pragma unroll
     for (int k = 0; k < (1 << BP_HLOG) / 64; ++k) S.tab[64 * k + lane] = 0u;
 
+    BP_MARK("plist_done");
+    if (BP_SKIP >= 4) {
+        if (lane == 0) csize[sidx] = P[m] & 1u;
+        return;
+    }
     uint32_t gop = 0, sop = 0, prev_end = 0;   // bytes written to global / staged; end of the last sequence
     int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
     for (int jw = -1; jw < (int)m; jw += 64) {
+        BP_MARK("win_begin");
         const int j = jw + (int)lane;
         const bool valid = j < (int)m;
         const uint32_t jj = valid ? (uint32_t)(j + 1) : 0u;          // index into P of this one
@@ -278,6 +299,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             if (CHAIN) S.chain[jj] = (uint16_t)jc1;   // what this one replaced: the next candidate down the chain
         }
         BP_FENCE();
+        BP_MARK("hash_done");
         // ---- candidates: forward length from the gaps; DEPTH of them along the chain, the one that saves most wins
         const uint32_t gq = q1 - qp1 - 1u;
         uint32_t len = 0, nb = 0, c1 = 0;
@@ -366,6 +388,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             if (!CHAIN) break;
             jc1 = have ? nextc : 0u;
         }
+        BP_MARK("cand_done");
         const uint32_t E = hv ? (uint32_t)q + len : (uint32_t)(q + 1);   // end of what this one codes (0 for the virtual one)
         // first one at or behind E: ones in front of bit E of the map
         uint32_t nxt;
@@ -380,8 +403,13 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
                 nxt = (uint32_t)wpre[w] + (uint32_t)__popc(lo & mlo) + (uint32_t)__popc(hi & mhi);
             }
         }
+        BP_MARK("nxt_done");
         // ---- which ones of the window are coded: follow nxt from `cur` by pointer doubling
         bool sel = false;
+        if (BP_SKIP >= 3) {
+            sink += nxt + E;
+            continue;
+        }
         if (cur < jw + 64) {   // (wave-uniform) otherwise the whole window lies inside an earlier match
             const uint32_t e0 = (uint32_t)(cur - jw);
             uint32_t jump = valid ? (nxt - (uint32_t)jw < 64u ? nxt - (uint32_t)jw : 64u) : 64u;   // nxt > j: always forward
@@ -403,6 +431,11 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             // the coded one whose successor lies outside the window hands over to the next window
             if (ex != 0ull) cur = (int)__builtin_amdgcn_readlane((int)nxt, (int)(__ffsll((long long)ex) - 1));
         }
+        BP_MARK("sel_done");
+        if (BP_SKIP >= 2) {
+            sink += sel ? nxt : 0u;
+            continue;
+        }
         // ---- sequences of the coded ones: match M (if hv) and tail run T over the zeros up to the next one
         const bool onM = sel && hv;
         const uint32_t rs = E + ((E == 0u || ((bp_bits(bm, E ? E - 1u : 0u) & 1u) != 0u)) ? 1u : 0u);
@@ -423,6 +456,13 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         const uint32_t szT = onT ? 3u + bp_len_ext(llT) + llT + bp_len_ext(lenT - 4u) : 0u;
         const uint32_t sincl = bp_scan_sum(szM + szT, lane);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        BP_MARK("sizes_done");
+        if (BP_SKIP >= 1) {
+            sink += total + sincl + ms + llT;
+            const uint32_t fm = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
+            prev_end = fm > prev_end ? fm : prev_end;
+            continue;
+        }
         // the window's bytes go to the staging area; what is staged leaves in coalesced dwords when the next window
         // would not fit (a window larger than the whole area is written to global memory directly)
         BP_FENCE();
@@ -441,8 +481,14 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             bp_put_seq(bm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
             sop += total;
         }
+        BP_MARK("emit_done");
         const uint32_t fmax = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
         prev_end = fmax > prev_end ? fmax : prev_end;
+    }
+    BP_MARK("loop_done");
+    if (BP_SKIP >= 1) {
+        if (lane == 0) csize[sidx] = (prev_end + sink) & 0xFFFu;
+        return;
     }
     // ---- last literals
     {
@@ -481,6 +527,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         BP_FENCE();
         bp_flush(S.stage, out + gop, sop, lane);
     }
+    if (BP_SKIP) op = (op & 0xFFFu) + (sink & 1u);
     if (lane == 0) csize[sidx] = op;
 }
 
@@ -493,8 +540,11 @@ int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scr
         return HHGT_ERR_ARG;
     }
     HIP_TRY(hipMemsetAsync(d_n_marked, 0, 4, st));
+    // development: extra (unused) dynamic LDS per workgroup caps how many workgroups a CU holds, which leaves LDS and
+    // wave slots to a kernel running beside this one on another stream
+    static const int lds_pad = getenv("HHGT_LZ4_LDS_PAD") ? atoi(getenv("HHGT_LZ4_LDS_PAD")) : 0;
 #define BP_LAUNCH(D)                                                                                                       \
-    hipLaunchKernelGGL((k_lz4_bitplanes<D>), dim3((uint32_t)n_blocks), dim3(128), 0, st, d_src, d_scratch, (uint64_t)slot_bytes, \
+    hipLaunchKernelGGL((k_lz4_bitplanes<D>), dim3((uint32_t)n_blocks), dim3(128), lds_pad, st, d_src, d_scratch, (uint64_t)slot_bytes, \
                        d_csize, d_marked, d_n_marked)
     if (depth <= 0) BP_LAUNCH(0);
     else if (depth == 1) BP_LAUNCH(1);

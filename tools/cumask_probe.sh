@@ -1,0 +1,13 @@
+#!/bin/bash
+# development: does splitting the CUs between the HBM-bound encode stream and the issue-bound LZ4 stream pay?
+run() { python bench.py "$@" --no-legs --no-cpu-baseline --no-check --steps 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],2), 'ms', round(d['value']/1e6,1), 'M/s', {k: round(v['ms']/3,1) if isinstance(v,dict) else round(v,1) for k,v in d['stages_ms_per_step_timed_region'].items()})"; }
+run
+run --cu-split 256,256
+run --cu-split 128,256
+run --cu-split 64,256
+run --cu-split 256,128
+run --cu-split 128,128
+run --cu-split 96,160
+run --cu-split 64,192
+run --cu-split 48,208
+run --cu-split 32,224

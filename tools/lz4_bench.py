@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--samples", type=int, default=2504)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--clevel", type=int, default=5)
+    ap.add_argument("--no-verify", action="store_true", help="development builds whose streams are not valid (timing only)")
     a = ap.parse_args()
     import torch
     from haplohyped_varawareml_amd import device as dev, synth
@@ -32,8 +33,9 @@ def main():
     ctx.pad_tail(res)
     chunk = lay.sc * lay.vc * 2
     dst, off, total = ctx.compress(res.G, chunk)
-    back, bad = ctx.decompress(dst, off, res.G.numel() // chunk, chunk)
-    assert bad == 0 and torch.equal(back, res.G)
+    if not a.no_verify:
+        back, bad = ctx.decompress(dst, off, res.G.numel() // chunk, chunk)
+        assert bad == 0 and torch.equal(back, res.G)
     ctx.profile(True)
     ctx.profile_reset()
     torch.cuda.synchronize()
