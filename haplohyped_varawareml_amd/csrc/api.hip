@@ -349,10 +349,10 @@ static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes,
     TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
     TRY(c->counts.ensure((size_t)n_regions * 4));
     TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
-    TRY(c->scan_tmp.ensure(scan_tmp_elems(n_regions) * 4));
+    TRY(c->scan_tmp.ensure(2 * scan_tmp_elems(n_regions) * 4));
     TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, min_line, cnt, st));
-    TRY(launch_scan_exclusive_u32(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), n_regions,
-                                  c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+    TRY(launch_scan_exclusive_u32_pair(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), nullptr, nullptr, n_regions,
+                                       c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
     return HHGT_OK;
 }
 
@@ -364,7 +364,7 @@ static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, 
     const uint32_t *d_nlines = c->prefix.as<uint32_t>() + n_regions;
     const size_t nl4 = ((size_t)max_lines + 1) * 4;
     TRY(c->nl.ensure(nl4));
-    TRY(c->scan_tmp.ensure(scan_tmp_elems(max_lines) * 4));
+    TRY(c->scan_tmp.ensure(2 * scan_tmp_elems(max_lines) * 4));
     DevBuf *per_line[] = {&c->l_soff, &c->l_lend, &c->l_pos, &c->l_refalt, &c->l_flags, &c->l_keep,
                           &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff, &c->k_lend, &c->k_meta,
                           &c->redo_list, &c->redo_flag};
@@ -384,10 +384,8 @@ static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, 
                                c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(),
                                c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(), c->l_keep.as<uint32_t>(),
                                c->l_cnew.as<uint32_t>(), cnt, st));
-        TRY(launch_scan_exclusive_u32(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), max_lines,
-                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
-        TRY(launch_scan_exclusive_u32(c->l_cnew.as<uint32_t>(), c->l_crun.as<uint32_t>(), max_lines,
-                                      c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
+        TRY(launch_scan_exclusive_u32_pair(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), c->l_cnew.as<uint32_t>(),
+                                           c->l_crun.as<uint32_t>(), max_lines, c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
         HIP_TRY(hipMemsetAsync(c->redo_flag.p, 0, (size_t)max_lines * 4, st));
         TRY(launch_compact_kept(text, nbytes, c->nl.as<uint32_t>(), d_nlines, max_lines, c->l_soff.as<uint32_t>(),
                                 c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(), c->l_refalt.as<uint32_t>(),

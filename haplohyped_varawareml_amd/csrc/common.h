@@ -131,6 +131,8 @@ int hhgt_profile_collect(hhgt_ctx *ctx);
 // scan.hip
 int launch_scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp,
                               size_t tmp_elems, hipStream_t st);
+int launch_scan_exclusive_u32_pair(const uint32_t *in_a, uint32_t *out_a, const uint32_t *in_b, uint32_t *out_b, uint64_t n,
+                                   uint32_t *d_tmp, size_t tmp_elems, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);
 
 // index.hip

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_down(const uint32_t *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nb];
 }
 
+// (declared in common.h)
 size_t scan_tmp_elems(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
 
 // d_out must hold n + 1 elements (d_out[n] = total).  In-place (d_in == d_out) is NOT supported.
@@ -114,3 +115,92 @@ int launch_scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, uint64_t n,
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
+
+// ---- two launches instead of three, and two arrays per pass: the arrays scanned on the encode path have at most a few
+// hundred tiles, so every downsweep block sums the partials in front of it itself (no k_scan_partials in between), and
+// the keep / chrom-run flags of the lines go through together.  B = 1 or 2 arrays.
+template <int B>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce_n(const uint32_t *__restrict__ in0, const uint32_t *__restrict__ in1,
+                                                              uint64_t n, uint32_t *__restrict__ partial, uint32_t nb)
+{
+    __shared__ uint32_t sm[8];
+    const uint32_t *ins[2] = {in0, in1};
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const uint64_t idx = base + (uint64_t)i * SCAN_BLOCK + threadIdx.x;
+            if (idx < n) s += ins[b][idx];
+        }
+        uint32_t tot;
+        block_excl_scan(s, &tot, sm);
+        if (threadIdx.x == 0) partial[(size_t)b * nb + blockIdx.x] = tot;
+    }
+}
+
+template <int B>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_down_n(const uint32_t *__restrict__ in0, const uint32_t *__restrict__ in1,
+                                                            uint64_t n, const uint32_t *__restrict__ partial, uint32_t nb,
+                                                            uint32_t *__restrict__ out0, uint32_t *__restrict__ out1)
+{
+    __shared__ uint32_t sm[8];
+    const uint32_t *ins[2] = {in0, in1};
+    uint32_t *outs[2] = {out0, out1};
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        // sum of the tiles in front of this one
+        uint32_t pre = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += SCAN_BLOCK) pre += partial[(size_t)b * nb + i];
+        uint32_t front;
+        block_excl_scan(pre, &front, sm);
+        uint32_t v[SCAN_ITEMS];
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const uint64_t idx = base + i;
+            v[i] = idx < n ? ins[b][idx] : 0;
+            s += v[i];
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(s, &tot, sm) + front;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) {
+            const uint64_t idx = base + i;
+            if (idx < n) outs[b][idx] = ex;
+            ex += v[i];
+        }
+        if (blockIdx.x == nb - 1 && threadIdx.x == 0) outs[b][n] = front + tot;
+    }
+}
+
+// out_a[0..n] / out_b[0..n] = exclusive prefix sums of in_a / in_b (out[n] = total); in_b == nullptr: one array.
+// d_tmp: 2 * scan_tmp_elems(n) elements.  More than SCAN_SHORT_MAX tiles: the three-launch form, one array at a time.
+#define SCAN_SHORT_MAX 2048u
+int launch_scan_exclusive_u32_pair(const uint32_t *in_a, uint32_t *out_a, const uint32_t *in_b, uint32_t *out_b, uint64_t n,
+                                   uint32_t *d_tmp, size_t tmp_elems, hipStream_t st)
+{
+    uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    if (nb == 0) nb = 1;
+    if (nb > SCAN_SHORT_MAX) {
+        int rc = launch_scan_exclusive_u32(in_a, out_a, n, d_tmp, tmp_elems, st);
+        if (rc == HHGT_OK && in_b) rc = launch_scan_exclusive_u32(in_b, out_b, n, d_tmp, tmp_elems, st);
+        return rc;
+    }
+    if (tmp_elems < 2 * (size_t)nb) {
+        hhgt_set_error("scan: tmp too small");
+        return HHGT_ERR_ARG;
+    }
+    if (in_b) {
+        hipLaunchKernelGGL(k_scan_reduce_n<2>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in_a, in_b, n, d_tmp, nb);
+        hipLaunchKernelGGL(k_scan_down_n<2>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in_a, in_b, n, d_tmp, nb, out_a, out_b);
+    } else {
+        hipLaunchKernelGGL(k_scan_reduce_n<1>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in_a, in_a, n, d_tmp, nb);
+        hipLaunchKernelGGL(k_scan_down_n<1>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in_a, in_a, n, d_tmp, nb, out_a, out_a);
+    }
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
