@@ -15,8 +15,12 @@
 //     key — exact sequential table semantics, 64 insertions at once.  (The first version keyed the table on the 12 bits
 //     at the one, LZ4's habit; on these planes that context is "a one and eleven zeros" nearly everywhere.  An equal
 //     first gap is what a match of ones needs to get past its first step: ratio 5.31 -> 5.86 at two candidates.)
-//   * match lengths come from comparing GAPS between ones (a few LDS reads per one), not bytes: equal gaps, then one
-//     plus the shorter of the first unequal pair; matches are pulled back over up to 8 literal zeros in front;
+//   * match lengths come from comparing GAPS between ones, not bytes: equal gaps, then one plus the shorter of the
+//     first unequal pair.  The gaps also exist as BYTES (clipped to 255), so a candidate is judged by one unaligned
+//     4-byte fetch, an xor and a count-trailing-zeros (three gaps + the open one); the longest agreement along the chain
+//     wins (picking by length packs tighter than picking by the local saving: the parse is greedy) and only the winner
+//     is worked out exactly from the positions, extended past the third gap where it still agrees, pulled back over up
+//     to 8 literal zeros in front, and priced;
 //   * every one decides locally between "match" and "literal" by cost (3 bytes per sequence against the literals and
 //     runs it replaces) and thereby where the next coded one is: the greedy parse is a linked list nxt(j), followed
 //     inside a window by pointer doubling (6 rounds), not by a serial loop;
@@ -25,18 +29,19 @@
 //
 // tools/sim/gapenc_ref.c states the same algorithm on the CPU, decision for decision; the kernel's streams are
 // compared with it byte for byte (tests/test_gpu_lz4_bitplanes.py) and decoded by liblz4 / the oracle like every
-// other stream.  Planes with a byte > 1 (missing calls, -9) or more than 1020 ones are left to the byte-wise
+// other stream.  Planes with a byte > 1 (missing calls, -9) or more than 636 ones are left to the byte-wise
 // encoder (csize = MARK; lz4.hip's kernel then runs in "marked streams only" mode).
 #include "common.h"
 
 #define BP_N 4096
-#define BP_MAXONES 764
+#define BP_MAXONES 636
 #define BP_STAGE 1024
 #define BP_HLOG 6
 #define BP_GAPCLIP 40
 #define BP_MINM 6
 #define BP_BACK 8
-#define BP_STEPS 8
+#define BP_STEPS 16   // exact extension of the chosen candidate
+#define BP_PICK 3     // full gaps the pick looks at (one dword of gap bytes)
 #ifdef BP_MARKS   // development: section markers in the ISA listing (hipcc -S -DBP_MARKS), tools/isa_sections.py counts per section
 #define BP_MARK(name) asm volatile("; ==MARK " name)
 #else
@@ -52,6 +57,7 @@ template <bool CHAIN> struct BpLds {
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
     uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
     uint16_t chain[CHAIN ? BP_MAXONES + 8 : 4];   // chain[j + 1] = (previous one with the same context hash) + 1, 0 = none
+    uint32_t gbw[(BP_MAXONES + 16) / 4];   // gap bytes: zeros behind the one with P-index i, clipped to 255 (255 from the last one on)
     uint8_t stage[BP_STAGE];         // output staged here, written out in coalesced dwords
 };
 
@@ -100,6 +106,13 @@ __device__ __forceinline__ uint32_t bp_bits(const uint32_t *bm, uint32_t q)
     const uint32_t i = q >> 5;
     const uint32_t lo = bm[i], hi = bm[i + 1];
     return __builtin_amdgcn_alignbit(hi, lo, q & 31u);
+}
+
+// four gap bytes starting at byte i of the gap array (two aligned dwords, one funnel shift)
+__device__ __forceinline__ uint32_t bp_gap4(const uint32_t *gbw, uint32_t i)
+{
+    const uint32_t w = i >> 2;
+    return __builtin_amdgcn_alignbit(gbw[w + 1u], gbw[w], (i & 3u) << 3);
 }
 
 __device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return x >= 15u ? (x - 15u) / 255u + 1u : 0u; }
@@ -271,6 +284,18 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         if (lane < 4u) P[m + 1u + lane] = (uint16_t)(BP_N + 1);
     }
     BP_FENCE();
+    if (DEPTH > 0) {   // gap bytes of all ones (a candidate is compared on them, 4 at a time)
+        uint8_t *gb = reinterpret_cast<uint8_t *>(S.gbw);
+        for (uint32_t i = lane; i < m + 8u; i += 64u) {
+            uint32_t g = 255u;
+            if (i < m) {
+                g = (uint32_t)P[i + 1u] - (uint32_t)P[i] - 1u;
+                g = g < 255u ? g : 255u;
+            }
+            gb[i] = (uint8_t)g;
+        }
+        BP_FENCE();
+    }
 #pragma unroll
     for (int k = 0; k < (1 << BP_HLOG) / 64; ++k) S.tab[64 * k + lane] = 0u;
 
@@ -300,59 +325,61 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         }
         BP_FENCE();
         BP_MARK("hash_done");
-        // ---- candidates: forward length from the gaps; DEPTH of them along the chain, the one that saves most wins
+        // ---- pick: the candidate with the longest forward agreement, judged on the gap BYTES — up to BP_PICK equal
+        //      gaps, then 1 + the smaller of the next pair.  All a candidate costs is one unaligned 4-byte fetch from
+        //      the gap bytes, an xor and a count-trailing-zeros; ties go to the nearer one.
         const uint32_t gq = q1 - qp1 - 1u;
         uint32_t len = 0, nb = 0, c1 = 0;
         bool hv = false;
-        int best_gain = -100000;
+        if (DEPTH > 0) {
+            const uint32_t a4 = bp_gap4(S.gbw, jj);
+            const uint32_t na4 = ~a4;
+            const uint32_t stop4 = ((na4 - 0x01010101u) & ~na4 & 0x80808080u) | 0xFF000000u;   // a 255 agrees with nothing; 3 gaps at most
+            int best = -1;
+            uint32_t bjq = 0, bk = 0;
 #pragma unroll 1
-        for (int dpt = 0; dpt < (DEPTH > 0 ? DEPTH : 1); ++dpt) {
-            const bool have = can && jc1 != 0u;
-            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
-            // Everything the first three gap comparisons need is fetched in ONE LDS round trip (the kernel is bound by
-            // dependent LDS latencies, not by issue): three P entries behind each of the two ones, the entry in front
-            // of the candidate, the next link of the chain.  Most candidates are decided within these.
-            const uint32_t jq = have ? jc1 : 1u;
-            const uint32_t cc1 = P[jq];                    // P[jc + 1] with jc = jc1 - 1
-            const uint32_t cp1 = P[jq - 1u];
-            const uint32_t b1 = P[jq + 1u], b2 = P[jq + 2u], b3 = P[jq + 3u];
-            const uint32_t a1 = qn1, a2 = P[jj + 2u], a3 = P[jj + 3u];
-            uint32_t nextc = 0;
-            if (CHAIN) nextc = S.chain[jq];
-            uint32_t clen = 0, costR = 0, tailz = 0;
-            {
-                uint32_t a = jj, b = jc1, pa = q1, pb = cc1;
-                bool act = have;
-                // steps 0..2 from registers
-                const uint32_t av[3] = {a1, a2, a3}, bv[3] = {b1, b2, b3};
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    if (act) {
-                        const uint32_t na = av[s], nbn = bv[s];
-                        const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
-                        costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
-                        if (ga != gb || a >= m) {
-                            const uint32_t z = ga < gb ? ga : gb;
-                            clen += 1u + z;
-                            tailz = ga - z;
-                            act = false;
-                        } else {
-                            clen += 1u + ga;
-                            ++a;
-                            ++b;
-                            pa = na;
-                            pb = nbn;
-                        }
-                    }
+            for (int dpt = 0; dpt < DEPTH; ++dpt) {
+                const bool have = can && jc1 != 0u;
+                if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+                const uint32_t jq = have ? jc1 : 1u;
+                const uint32_t b4 = bp_gap4(S.gbw, jq);
+                uint32_t nextc = 0;
+                if (CHAIN) nextc = S.chain[jq];
+                const uint32_t x = (a4 ^ b4) | stop4;
+                const uint32_t k = (uint32_t)__builtin_ctz(x) >> 3;                     // agreeing gaps: 0..3
+                const uint32_t below = (1u << (8u * k)) - 1u;
+                const uint32_t sumg = __builtin_amdgcn_sad_u8(a4 & below, 0u, k + 1u);  // their zeros + their ones + this one
+                const uint32_t za = (a4 >> (8u * k)) & 0xFFu, zb = (b4 >> (8u * k)) & 0xFFu;
+                const int score = (int)(sumg + (za < zb ? za : zb));
+                if (have && score > best) {
+                    best = score;
+                    bjq = jq;
+                    bk = k;
                 }
-                // longer agreements: one round trip per further gap
-                for (int s = 3; s <= BP_STEPS; ++s) {
+                if (!CHAIN) break;
+                jc1 = have ? nextc : 0u;
+            }
+            // ---- the chosen one, exactly (positions from P): agreement may continue past the third gap (periodic
+            //      planes; rare), then the costs decide between this match and literals
+            const bool got = best >= 0;
+            if (__builtin_amdgcn_ballot_w64(got) != 0ull) {
+                const uint32_t jq = got ? bjq : 1u;
+                const uint32_t cc1 = P[jq], cp1 = P[jq - 1u];
+                uint32_t a = jj + bk, b = jq + bk;          // P-indices of the ones the first open comparison starts at
+                uint32_t pa = P[a], na = P[a + 1u], pb = P[b], nbn = P[b + 1u];
+                uint32_t clen = pa - q1, costR = 0, tailz = 0;
+#pragma unroll
+                for (uint32_t s = 0; s < BP_PICK; ++s) {
+                    const uint32_t g = (a4 >> (8u * s)) & 0xFFu;
+                    costR += s < bk ? 1u + (g >= BP_MINM + 1u ? 4u : g) : 0u;
+                }
+                bool act = got;
+                for (uint32_t s = bk;; ++s) {   // (per lane: s starts at the lane's own bk; the trip count is what the wave needs)
                     if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
                     if (act) {
-                        const uint32_t na = P[a + 1u], nbn = P[b + 1u];
                         const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
                         costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
-                        if (ga != gb || a >= m || s >= BP_STEPS) {   // a = j + 1: "a + 1 >= m" of the reference
+                        if (s < BP_PICK || ga != gb || ga >= 255u || a >= m || s >= BP_STEPS) {
                             const uint32_t z = ga < gb ? ga : gb;
                             clen += 1u + z;
                             tailz = ga - z;
@@ -363,30 +390,28 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
                             ++b;
                             pa = na;
                             pb = nbn;
+                            na = P[a + 1u];
+                            nbn = P[b + 1u];
                         }
                     }
                 }
-            }
-            if (have) {
-                const uint32_t gc = cc1 - cp1 - 1u;
-                uint32_t cnb = gq < gc ? gq : gc;
-                cnb = cnb < BP_BACK ? cnb : BP_BACK;
-                const uint32_t costH = 3u + (clen + cnb >= 19u ? 1u : 0u) - cnb + (tailz >= BP_MINM ? 3u : tailz);
-                uint32_t end = (uint32_t)q + clen;
-                end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
-                // signed compares: costH may go below zero when many zeros are pulled in
-                const int gain = (int)costR - (int)costH;
-                const bool ok = gain > 0 && (int)end - q >= 4 && (int)end - (q - (int)cnb) >= BP_MINM && q <= BP_MFLIMIT;
-                if (ok && gain > best_gain) {
-                    best_gain = gain;
-                    hv = true;
-                    len = end - (uint32_t)q;
-                    nb = cnb;
-                    c1 = cc1;
+                if (got) {
+                    const uint32_t gc = cc1 - cp1 - 1u;
+                    uint32_t cnb = gq < gc ? gq : gc;
+                    cnb = cnb < BP_BACK ? cnb : BP_BACK;
+                    const uint32_t costH = 3u + (clen + cnb >= 19u ? 1u : 0u) - cnb + (tailz >= BP_MINM ? 3u : tailz);
+                    uint32_t end = (uint32_t)q + clen;
+                    end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
+                    // signed compares: costH may go below zero when many zeros are pulled in
+                    const int gain = (int)costR - (int)costH;
+                    if (gain > 0 && (int)end - q >= 4 && (int)end - (q - (int)cnb) >= BP_MINM && q <= BP_MFLIMIT) {
+                        hv = true;
+                        len = end - (uint32_t)q;
+                        nb = cnb;
+                        c1 = cc1;
+                    }
                 }
             }
-            if (!CHAIN) break;
-            jc1 = have ? nextc : 0u;
         }
         BP_MARK("cand_done");
         const uint32_t E = hv ? (uint32_t)q + len : (uint32_t)(q + 1);   // end of what this one codes (0 for the virtual one)

@@ -46,7 +46,7 @@ def edge_planes():
     out = [z.copy()]
     for pos in ([0], [N - 1], [0, N - 1], [1], [5], [6], [7], [N - 5], [N - 6], [N - 12], [N - 13], [2000], [63], [64], [65],
                 list(range(0, N, 7)), list(range(3, N, 64)), list(range(0, N, 2)), list(range(100, 140)), [10, 11, 12, 30, 31, 32, 50],
-                list(range(0, 764 * 5, 5)), list(range(0, 765 * 5, 5))):
+                list(range(0, 636 * 5, 5)), list(range(0, 637 * 5, 5))):
         a = z.copy()
         a[pos] = 1
         out.append(a)
@@ -115,7 +115,7 @@ def test_random_planes_match_the_reference(ctx, ref, scale, seed):
         n_ref += 1
         assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref ({got[k].size} vs {want.size} bytes)"
         assert np.array_equal(oracle.lz4_decompress(got[k], N), pl)
-    assert n_ref >= 120
+    assert n_ref >= (120 if scale < 2 else 80)   # dense planes beyond 636 ones go to the byte-wise encoder
     if scale == 1.0:
         assert planes.size / total > 5.0          # the ratio the byte-wise encoder reaches on such planes is 5.12
 
@@ -135,7 +135,7 @@ def test_effort_levels_match_the_reference(ctx, ref, clevel, depth):
         want = ref(pl, depth)
         assert np.array_equal(got[k], want), f"clevel {clevel}: plane {k} differs from gapenc_ref(depth={depth})"
     ratio = planes.size / total
-    lo = {0: 3.0, 1: 5.2, 2: 5.4, 4: 5.6, 8: 5.7, 16: 5.75}[depth]
+    lo = {0: 3.0, 1: 5.2, 2: 5.5, 4: 5.7, 8: 5.8, 16: 5.85}[depth]
     assert ratio > lo, (clevel, ratio)
 
 
@@ -153,7 +153,7 @@ def test_edge_planes(ctx, ref):
 
 
 def test_non_binary_and_dense_planes_fall_back(ctx, ref):
-    """a byte > 1 (missing call -9 = 0xF7) or more than 1020 ones: the byte-wise encoder codes the stream — mixed
+    """a byte > 1 (missing call -9 = 0xF7) or more than 636 ones: the byte-wise encoder codes the stream — mixed
     with bit-plane streams in the same block and chunk"""
     rng = np.random.default_rng(9)
     planes = bench_like(rng, 16)

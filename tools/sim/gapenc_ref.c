@@ -9,9 +9,11 @@
 //     stream order (on the GPU: one ds_wrxchg_rtn_b32 per 64 ones — the LDS serves equal addresses in lane order);
 //     what an insertion replaces is remembered (chain), so `depth` candidates can be tried per one: the table's entry,
 //     what that one replaced, ... — the candidate that saves most wins (depth 0: no hash matches, runs only)
-//   * candidate jc = previous one with that hash.  Forward length from the GAPS: while the gaps behind the two ones
-//     are equal (at most 8 of them) take gap + 1, then 1 + the smaller gap.  costR = what coding the covered ones
-//     as literals (+ offset-1 runs for gaps >= 7) would take; tailz = zeros left of the last covered one's gap
+//   * candidates jc = previous ones with that key, most recent first.  The PICK among them is made on the gap bytes
+//     (gaps clipped to 255, a 255 agrees with nothing): while the gaps behind the two ones are equal (at most 3 of
+//     them) take gap + 1, then 1 + the smaller gap; the longest wins, ties go to the nearer one.  Only the winner is
+//     evaluated exactly: its agreement may go on (to 16 gaps), costR = what coding the covered ones as literals
+//     (+ offset-1 runs for gaps >= 7) would take; tailz = zeros left of the last covered one's gap
 //   * pulled back over nb = min(8, zeros in front of q, zeros in front of the candidate) literal zeros
 //   * taken (hv) iff cheaper than costR, forward part >= 4, total >= 6, q <= mflimit
 //   * E = end of what the one codes (match end, else q + 1); nxt = first one at or behind E
@@ -21,12 +23,13 @@
 #include <stdint.h>
 #include <string.h>
 
-#define N_MAXONES 764
+#define N_MAXONES 636
 #define HLOG 6
 #define GAPCLIP 40
 #define MINM 6
 #define BACK 8
-#define STEPS 8
+#define STEPS 16   /* exact extension of the chosen candidate */
+#define PICK 3     /* full gaps the pick looks at */
 
 static int put_len(uint8_t *out, int op, int r)
 {
@@ -63,6 +66,14 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
         }
     }
     P[m + 1] = P[m + 2] = n + 1;
+    // gap bytes: GB[i] = zeros behind the one with P-index i (i = 0: the virtual one in front), clipped to 255; the last
+    // real one and everything behind it read 255 = "agrees with nothing"
+    static __thread uint8_t GB[4100 + 8];
+    for (int i = 0; i < m; ++i) {
+        const int g = P[i + 1] - P[i] - 1;
+        GB[i] = (uint8_t)(g < 255 ? g : 255);
+    }
+    for (int i = m; i < m + 8; ++i) GB[i] = 255;
     uint32_t tab[1 << HLOG];
     memset(tab, 0, sizeof(tab));
     const int mflimit = n - 12, matchlimit = n - 5;
@@ -76,34 +87,49 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
             int jc = (int)tab[idx] - 1;
             tab[idx] = (uint32_t)(j + 1);
             chain[j] = jc;
-            int best_gain = -100000;
+            // ---- pick: the candidate with the longest forward agreement, judged on the gap BYTES (gaps clipped to 255;
+            // 255 never agrees): up to 3 equal gaps, then 1 + the smaller of the next pair.  Ties go to the nearer one.
+            int best_score = -1, bj = -1, bk = 0;
             for (int dpt = 0; dpt < depth && jc >= 0; ++dpt, jc = chain[jc]) {
+                int k = 0, score = 0;
+                while (k < PICK && GB[j + 1 + k] == GB[jc + 1 + k] && GB[j + 1 + k] != 255) {
+                    score += GB[j + 1 + k] + 1;
+                    ++k;
+                }
+                const int za = GB[j + 1 + k], zb = GB[jc + 1 + k];
+                score += 1 + (za < zb ? za : zb);
+                if (score > best_score) { best_score = score; bj = jc; bk = k; }
+            }
+            // ---- the chosen one, exactly: agreement continues past the third gap (rarely: periodic planes), then the
+            // costs decide between this match and literals
+            if (bj >= 0) {
+                jc = bj;
                 const int cc = P[jc + 1] - 1;
-                int clen = 0, cnb;
-                int a = j, b = jc, pa = q + 1, pb = cc + 1, costR = 0, tailz = 0;
-                for (int s = 0;; ++s) {
-                    const int na = P[a + 2], nbn = P[b + 2];
-                    const int ga = na - pa - 1, gb = nbn - pb - 1;
+                int a = j + bk, b = jc + bk, clen = P[a + 1] - P[j + 1], costR = 0, tailz = 0;
+                for (int s = 0; s < bk; ++s) {
+                    const int g = GB[j + 1 + s];
+                    costR += 1 + (g >= MINM + 1 ? 4 : g);
+                }
+                for (int s = bk;; ++s) {
+                    const int ga = P[a + 2] - P[a + 1] - 1, gb = P[b + 2] - P[b + 1] - 1;
                     costR += 1 + (ga >= MINM + 1 ? 4 : ga);
-                    if (ga != gb || a + 1 >= m || s >= STEPS) {
+                    if (s < PICK || ga != gb || ga >= 255 || a + 1 >= m || s >= STEPS) {   // s < PICK: the pick's own verdict
                         const int z = ga < gb ? ga : gb;
                         clen += 1 + z;
                         tailz = ga - z;
                         break;
                     }
                     clen += 1 + ga;
-                    ++a; ++b; pa = na; pb = nbn;
+                    ++a; ++b;
                 }
                 const int gq = q + 1 - P[j] - 1, gc = cc + 1 - P[jc] - 1;
-                cnb = gq < gc ? gq : gc;
+                int cnb = gq < gc ? gq : gc;
                 if (cnb > BACK) cnb = BACK;
                 const int costH = 3 + (clen + cnb >= 19 ? 1 : 0) - cnb + (tailz >= MINM ? 3 : tailz);
                 int end = q + clen;
                 if (end > matchlimit) end = matchlimit;
                 const int gain = costR - costH;
-                if (gain > 0 && end - q >= 4 && end - (q - cnb) >= MINM && q <= mflimit && gain > best_gain) {
-                    best_gain = gain; hv = 1; len = end - q; nb = cnb; c = cc;
-                }
+                if (gain > 0 && end - q >= 4 && end - (q - cnb) >= MINM && q <= mflimit) { hv = 1; len = end - q; nb = cnb; c = cc; }
             }
         }
         const int e = hv ? q + len : q + 1;
