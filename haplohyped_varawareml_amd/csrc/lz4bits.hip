@@ -35,7 +35,9 @@
 
 #define BP_N 4096
 #define BP_MAXONES 636
-#define BP_STAGE 1024
+#ifndef BP_STAGE
+#define BP_STAGE 1024   // 512 would let 16 workgroups share a CU (LZ4 stage -5 %) but leaves no wave slots to the index kernel of the next shard running beside it: the step gets slower (28.8 against 27.2 ms)
+#endif
 #define BP_HLOG 6
 #define BP_GAPCLIP 40
 #define BP_MINM 6
