@@ -337,8 +337,9 @@ static int encode_check_args(hhgt_ctx *c, const void *d_text, uint64_t nbytes, c
         hhgt_set_error("encode: d_G is NULL");
         return HHGT_ERR_ARG;
     }
-    (void)c;
-    return parse_region_host(region, rf);
+    const int rc = parse_region_host(region, rf);
+    rf->keep_multi = c->keep_multi;
+    return rc;
 }
 
 // stage 1: newline index of the block -> prefix[n_regions] holds the line count (device).  min_line: a record with S
@@ -711,6 +712,13 @@ extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)
         return HHGT_ERR_ARG;
     }
     c->clevel = clevel;
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_set_keep_multiallelic(hhgt_ctx *c, int on)
+{
+    if (!c) return HHGT_ERR_ARG;
+    c->keep_multi = on ? 1 : 0;
     return HHGT_OK;
 }
 

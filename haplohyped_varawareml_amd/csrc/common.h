@@ -56,6 +56,7 @@ struct RegionFilter {
     int contig_len;   // 0 = no filter
     int has_range;
     long long beg, end;  // 1-based inclusive
+    int keep_multi;      // non-reference mode: multi-allelic SNP sites pass the record filter (hhgt_set_keep_multiallelic)
 };
 
 // index stage geometry: one wave scans INDEX_REGION bytes, at most INDEX_CAP newlines in it
@@ -107,6 +108,7 @@ struct hhgt_ctx {
     std::vector<uint64_t> run_first_kept;
     std::vector<std::string> run_names_host;
     int clevel = 5;        // Blosc clevel analogue (reference: compression_opts[4] = 5)
+    int keep_multi = 0;    // hhgt_set_keep_multiallelic
     // profiling
     int profiling = 0;
     double stage_ms[HHGT_N_STAGES] = {0};

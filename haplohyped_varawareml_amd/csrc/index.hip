@@ -322,8 +322,16 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                     else {
                         // isSNP (cpp/vcfpp.h:990-1000): |REF| <= 1, n_allele <= 2, ALT in {A,C,G,T}
                         uint32_t reflen = fe[3] - fs[3], altlen = fe[4] - fs[4];
-                        uint32_t a = altlen == 1 ? rd(fs[4]) : 0;
+                        uint32_t a = altlen >= 1 ? rd(fs[4]) : 0;
                         bool snp = reflen == 1 && altlen == 1 && (a == 'A' || a == 'C' || a == 'G' || a == 'T');
+                        if (rf->keep_multi && reflen == 1 && altlen > 1 && (altlen & 1u)) {
+                            // non-reference mode: "B,B[,B...]" with every B in {A,C,G,T}
+                            snp = true;
+                            for (uint32_t q = 0; snp && q < altlen; ++q) {
+                                const uint32_t ch = rd(fs[4] + q);
+                                snp = (q & 1u) ? ch == ',' : (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+                            }
+                        }
                         if (!snp)
                             flags |= LF_DROP_FILTER;
                         else {

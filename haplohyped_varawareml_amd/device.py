@@ -208,6 +208,11 @@ class Context:
             check(self.lib.hhgt_pad_tail(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end),
                                          _ptr(res.G), _stream()))
 
+    def set_keep_multiallelic(self, on=True):
+        """NON-REFERENCE mode: multi-allelic SNP sites pass the record filter (the reference's isSNP drops them);
+        genotypes carry allele indices > 1.  Off by default."""
+        check(self.lib.hhgt_set_keep_multiallelic(self.h, 1 if on else 0))
+
     def set_clevel(self, clevel):
         """Blosc clevel analogue: 3..9 (default 5, the reference's setting) full matcher; 1..2 run-only"""
         check(self.lib.hhgt_set_clevel(self.h, int(clevel)))

@@ -183,6 +183,11 @@ uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int types
  * hash + run candidates; 1..2: run candidate only (LZ4 "acceleration": faster, lower ratio); 7..9: plus long-run
  * sources, backward extension and full extension of every match (about 40 % slower, ~10 % tighter).  Every level emits the same LZ4 block format. */
 int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
+/* NON-REFERENCE mode (measured separately and labelled so): with on != 0 the record filter also
+ * keeps multi-allelic SNP sites — |REF| = 1 and ALT a comma-separated list of single bases from {A,C,G,T} — where the
+ * reference's isSNP (cpp/vcfpp.h:990-1000) drops every record with more than two alleles.  Genotypes then carry the
+ * allele index as int8 (cpp/vcfpp.h:574), alt[] holds the first ALT base.  Default 0: the reference's filter. */
+int hhgt_set_keep_multiallelic(hhgt_ctx *ctx, int on);
 int hhgt_compress_chunks(hhgt_ctx *ctx, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
                          int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
                          uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream);

@@ -43,6 +43,8 @@ typedef struct {
  * chrom: [cap][32] NUL padded CHROM text, may be NULL.
  * region: "" / NULL = no filter; "chrN" ; "chrN:beg-end" (1-based inclusive, tabix style).
  * Returns n_kept, or -1 if cap is too small / -2 on malformed input. */
+/* labelled NON-REFERENCE filter mode (include/hhgt.h hhgt_set_keep_multiallelic): multi-allelic SNP sites are kept */
+void oracle_set_keep_multiallelic(int on);
 int64_t oracle_vcf_encode(const uint8_t *text, size_t n, const char *region, int n_samples,
                           size_t cap, int8_t *G, uint32_t *start, uint32_t *stop,
                           uint8_t *ref, uint8_t *alt, char *chrom, oracle_vcf_stats *st);

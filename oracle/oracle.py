@@ -43,6 +43,8 @@ def lib():
         build()
         L = C.CDLL(_LIB)
         u8p = C.c_void_p
+        L.oracle_set_keep_multiallelic.argtypes = [C.c_int]
+        L.oracle_set_keep_multiallelic.restype = None
         L.oracle_vcf_encode.restype = C.c_int64
         L.oracle_vcf_encode.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_int, C.c_size_t, u8p, u8p,
                                         u8p, u8p, u8p, u8p, C.POINTER(VcfStats)]
@@ -91,8 +93,9 @@ def header_samples(text):
     return [tb[int(o):int(o) + int(l)].decode() for o, l in zip(off[:n], ln[:n])]
 
 
-def vcf_encode(text, n_samples, region="", cap=None, want_chrom=False):
-    """-> dict(G int8 [S, n_kept, 2], start, stop, ref, alt, chrom?, stats)"""
+def vcf_encode(text, n_samples, region="", cap=None, want_chrom=False, keep_multiallelic=False):
+    """-> dict(G int8 [S, n_kept, 2], start, stop, ref, alt, chrom?, stats).  keep_multiallelic: the labelled
+    non-reference filter mode of include/hhgt.h (multi-allelic SNP sites kept)"""
     t = _as_u8(text)
     if cap is None:
         cap = int(np.count_nonzero(t == 10)) + 1
@@ -104,8 +107,12 @@ def vcf_encode(text, n_samples, region="", cap=None, want_chrom=False):
     alt = np.zeros(cap, np.uint8)
     chrom = np.zeros((cap, 32), np.uint8) if want_chrom else None
     st = VcfStats()
-    n = lib().oracle_vcf_encode(_ptr(t), t.size, region.encode(), n_samples, cap, _ptr(G), _ptr(start),
-                                _ptr(stop), _ptr(ref), _ptr(alt), _ptr(chrom), C.byref(st))
+    lib().oracle_set_keep_multiallelic(1 if keep_multiallelic else 0)
+    try:
+        n = lib().oracle_vcf_encode(_ptr(t), t.size, region.encode(), n_samples, cap, _ptr(G), _ptr(start),
+                                    _ptr(stop), _ptr(ref), _ptr(alt), _ptr(chrom), C.byref(st))
+    finally:
+        lib().oracle_set_keep_multiallelic(0)
     if n < 0:
         raise RuntimeError(f"oracle_vcf_encode failed rc={n} stats={st.asdict()}")
     out = dict(G=np.ascontiguousarray(G[:n_samples, :n]), start=start[:n], stop=stop[:n], ref=ref[:n],

@@ -122,13 +122,27 @@ static void split_fixed(const uint8_t *s, const uint8_t *e, fixed_t *fx)
     fx->f[9] = p;
 }
 
+/* NON-REFERENCE mode switch (include/hhgt.h hhgt_set_keep_multiallelic): 0 = the reference's filter */
+static int g_keep_multi = 0;
+void oracle_set_keep_multiallelic(int on) { g_keep_multi = on ? 1 : 0; }
+
 /* cpp/vcfpp.h:990-1000: REF length <= 1, n_allele <= 2, ALT[0] in {A,C,G,T} exactly. */
 static int is_snp(const fixed_t *fx)
 {
     size_t reflen = (size_t)(fx->fe[3] - fx->f[3]);
     size_t altlen = (size_t)(fx->fe[4] - fx->f[4]);
     if (reflen != 1) return 0;
-    if (altlen != 1) return 0; /* a comma => n_allele>2; longer => not "A|C|G|T"; "." => n_allele==1 */
+    if (altlen != 1) { /* a comma => n_allele>2; longer => not "A|C|G|T"; "." => n_allele==1 */
+        if (!g_keep_multi || altlen < 3 || !(altlen & 1)) return 0;
+        for (size_t q = 0; q < altlen; ++q) {   /* labelled mode: "B,B[,B...]", every B one of A C G T */
+            uint8_t ch = fx->f[4][q];
+            if (q & 1) {
+                if (ch != ',') return 0;
+            } else if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'))
+                return 0;
+        }
+        return 1;
+    }
     uint8_t a = *fx->f[4];
     return a == 'A' || a == 'C' || a == 'G' || a == 'T';
 }

@@ -16,10 +16,13 @@ def main():
     ap.add_argument("--config", choices=["c2", "c4"], default="c4")
     ap.add_argument("--variants", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--keep-multiallelic", action="store_true",
+                    help="the labelled NON-REFERENCE filter mode (multi-allelic SNP sites kept, allele indices > 1)")
     a = ap.parse_args()
     import torch
     from haplohyped_varawareml_amd import device as dev, synth
     ctx = dev.Context(0)
+    ctx.set_keep_multiallelic(a.keep_multiallelic)
     if a.config == "c2":
         S, V, contig, seed = 1000, a.variants or 50_000, "chr22", 22
         tab = synth.variant_table(seed, V, S)
@@ -44,7 +47,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     st = ctx.profile_read()
-    print(json.dumps(dict(config=a.config, variants=V, samples=S, text_bytes=n, kept=res.n_kept,
+    print(json.dumps(dict(config=a.config, mode="keep_multiallelic (non-reference)" if a.keep_multiallelic else "reference filter", variants=V, samples=S, text_bytes=n, kept=res.n_kept,
                           general_lines=res.stats["n_general_lines"], ms_per_step=dt * 1e3,
                           variants_per_s=V / dt, ratio=res.G.numel() / int(off[-1].item()),
                           stages_ms={k: v["ms"] / a.steps for k, v in st.items()})))
