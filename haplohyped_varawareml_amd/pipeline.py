@@ -167,7 +167,19 @@ class _DeviceBgzfBlocks:
             n = self._inflate_into(dbuf, 0)
             self._check()
             cut = self._cut(dbuf, n)
-            head = dbuf[:min(cut, 8 << 20)].cpu().numpy()
+            # the '#' lines only: the header ends behind the first newline that is not followed by '#' (searched on
+            # the device, within the same 64 MiB bound the host reader accepts)
+            lim = min(cut, 64 << 20)
+            hend = lim
+            if lim > 1:
+                seg = dbuf[:lim]
+                if int(seg[0]) != 35:
+                    hend = 0
+                else:
+                    m = torch.nonzero((seg[:-1] == 10) & (seg[1:] != 35))
+                    if m.numel():
+                        hend = int(m[0]) + 1
+            head = dbuf[:max(hend, min(lim, 1 << 12))].cpu().numpy()
         copy_stream.synchronize()
         self._tail = (n, cut)
         return (head if cut else None), cut

@@ -135,6 +135,35 @@ def test_stream_file_device_inflate_matches_host_inflate(ctx, tmp_path):
     assert np.array_equal(Gh, Gd) and np.array_equal(sh, sd)
 
 
+def test_stream_file_device_inflate_accepts_a_long_header(ctx, tmp_path):
+    """a header of more than 8 MiB (tens of thousands of ##contig lines): the device-inflate path finds its end on the
+    device and hands all of it to the header parser, as the host path does (up to 64 MiB)"""
+    from haplohyped_varawareml_amd import pipeline
+    S = 40
+    tab = synth.variant_table(3, 600, S)
+    text, _ = synth.render_fixed_numpy("chr3", tab, S, seed=3)
+    text = bytes(text)
+    first_nl = text.index(b"\n") + 1
+    contigs = b"".join(b"##contig=<ID=scaffold_%07d,length=%d,assembly=an_assembly_with_a_long_name_%060d>\n" % (i, 1000 + i, i)
+                       for i in range(80000))
+    assert len(contigs) > (9 << 20)
+    big = text[:first_nl] + contigs + text[first_nl:]
+    path = tmp_path / "h.vcf.gz"
+    write_bgzf(str(path), big, level=1)
+    out = {}
+    for mode in (False, True):
+        cols = []
+        fs = pipeline.stream_file(ctx, str(path), sc=64, vc=512, block_bytes=16 << 20, compress=False, device_inflate=mode,
+                                  on_columns=lambda G, n, framed: cols.append(G.cpu().numpy().copy()))
+        out[mode] = (fs.n_kept, np.concatenate(cols))
+    assert out[True][0] == out[False][0] == 600
+    assert np.array_equal(out[True][1], out[False][1])
+    # the ingest engine (compressed output) takes the same file with either inflater
+    for mode in (False, True):
+        fs = pipeline.stream_file(ctx, str(path), sc=64, vc=512, compress=True, device_inflate=mode)
+        assert fs.n_kept == 600 and fs.n_samples == S
+
+
 def test_fuzzed_members_terminate_and_stay_in_bounds(ctx):
     """400 members, each garbled differently (bit flips, random runs, truncated tables): every wave must finish, flag or
     decode its member, and never write outside the member's slice (guard bytes around the output stay intact)."""
