@@ -431,7 +431,9 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             }
         }
         BP_MARK("nxt_done");
-        // ---- which ones of the window are coded: follow nxt from `cur` by pointer doubling
+        // ---- which ones of the window are coded: follow nxt from `cur` by pointer doubling.  (Measured against the plain
+        //      walk on the scalar unit — one v_readlane + 5 scalar instructions per coded one, half the vector instructions:
+        //      14.8 against 13.0 ms per step.  A wave's dependent chain is what counts, not its instruction total.)
         bool sel = false;
         if (BP_SKIP >= 3) {
             sink += nxt + E;
