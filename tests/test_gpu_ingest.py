@@ -179,3 +179,49 @@ def test_sites_only(ctx, tmp_path):
     res = run_engine(ctx, [(torch.frombuffer(bytearray(text), dtype=torch.uint8), "chr5")], sites_only=True, block_bytes=1 << 20)[0]
     o = oracle.vcf_encode(text, 0, region="chr5")
     assert res["S"] == 0 and not res["chunks"] and np.array_equal(np.concatenate(res["start"]), o["start"])
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HHGT_FUZZ_SEEDS", "12")))))   # HHGT_FUZZ_SEEDS=200: a longer soak
+def test_randomized_engine_matches_oracle(ctx, tmp_path, seed):
+    """random sample counts (some beyond 760: the hopping index), variant counts, chunk geometries, block sizes, thread
+    counts and sources; two or three inputs per engine so that the per-input state is recycled; every matrix, table and
+    chunk against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    sc = int(rng.choice([16, 64, 128]))
+    vc = int(rng.choice([256, 512, 4096, 8192]))
+    fmt = dev.BLOSC1 if seed % 2 else dev.BLOSC2
+    jobs, expect = [], []
+    for k in range(int(rng.integers(2, 4))):
+        S = int(rng.choice([1, 3, 17, 64, 65, 300, 801, 1500]))
+        V = int(rng.integers(1, 60000 // max(S // 8, 1) + 2))
+        contig = f"chr{int(rng.integers(1, 23))}"
+        kind = ["fixed", "mixed"][int(rng.integers(0, 2))] if S <= 300 and V <= 3000 else "fixed"
+        if kind == "fixed":
+            text, _ = synth.render_fixed_numpy(contig, synth.variant_table(seed * 10 + k, V, S), S, seed=seed * 10 + k)
+            text = bytes(text)
+        else:
+            text = synth.render_mixed(contig, V, S, seed=seed * 10 + k)
+        src_kind = ["bgzf", "plain", "memory", "device"][int(rng.integers(0, 4))]
+        if src_kind == "memory":
+            src = torch.frombuffer(bytearray(text), dtype=torch.uint8).pin_memory()
+        else:
+            src = str(tmp_path / (f"in{k}.vcf" + (".gz" if src_kind in ("bgzf", "device") else "")))
+            if src_kind in ("bgzf", "device"):
+                write_bgzf(src, text, level=int(rng.choice([1, 6])))
+            else:
+                open(src, "wb").write(text)
+        region = contig if rng.random() < 0.7 else ""
+        jobs.append((src, region, src_kind))
+        expect.append((text, S, region))
+    # one engine per inflater mode (device inflate is an engine option): group the jobs
+    for mode in (False, True):
+        sel = [i for i, j in enumerate(jobs) if (j[2] == "device") == mode]
+        if not sel:
+            continue
+        line_max = max(len(expect[i][0]) // max(expect[i][0].count(b"\n"), 1) for i in sel) * 3
+        bb = int(max(int(rng.choice([1 << 20, 3 << 20, 8 << 20])), line_max + (1 << 16)))
+        res = run_engine(ctx, [(jobs[i][0], jobs[i][1]) for i in sel], sc=sc, vc=vc, fmt=fmt, device_inflate=mode,
+                         block_bytes=bb, n_threads=int(rng.integers(1, 6)))
+        for n, i in enumerate(sel):
+            text, S, region = expect[i]
+            check_against_oracle(res[n], text, S, region, sc, vc)
