@@ -268,19 +268,23 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     wpre[lane] = (uint16_t)(incl - cnt);
     BP_FENCE();
     {   // the list of ones
+        // (the two halves of the lane's 64 positions one after the other: each round is a count-trailing-zeros, a clear
+        // and a store, and there are as many rounds as the fullest 32-position word has ones — twice ~6 — where one loop
+        // over the 64-bit word ran ~11 rounds of twice the work)
         uint32_t lo = wlo, hi = whi, at = incl - cnt + 1u;
         if (lane == 0) P[0] = 0;
-        while (__builtin_amdgcn_ballot_w64((lo | hi) != 0u) != 0ull) {
-            if ((lo | hi) != 0u) {
-                uint32_t t;
-                if (lo) {
-                    t = (uint32_t)__builtin_ctz(lo);
-                    lo &= lo - 1u;
-                } else {
-                    t = 32u + (uint32_t)__builtin_ctz(hi);
-                    hi &= hi - 1u;
-                }
-                P[at++] = (uint16_t)(64u * lane + t + 1u);
+        uint32_t base = 64u * lane + 1u;
+        while (__builtin_amdgcn_ballot_w64(lo != 0u) != 0ull) {
+            if (lo != 0u) {
+                P[at++] = (uint16_t)(base + (uint32_t)__builtin_ctz(lo));
+                lo &= lo - 1u;
+            }
+        }
+        base += 32u;
+        while (__builtin_amdgcn_ballot_w64(hi != 0u) != 0ull) {
+            if (hi != 0u) {
+                P[at++] = (uint16_t)(base + (uint32_t)__builtin_ctz(hi));
+                hi &= hi - 1u;
             }
         }
         if (lane < 4u) P[m + 1u + lane] = (uint16_t)(BP_N + 1);
