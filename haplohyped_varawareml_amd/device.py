@@ -214,7 +214,8 @@ class Context:
         check(self.lib.hhgt_set_keep_multiallelic(self.h, 1 if on else 0))
 
     def set_clevel(self, clevel):
-        """Blosc clevel analogue: 3..9 (default 5, the reference's setting) full matcher; 1..2 run-only"""
+        """Blosc clevel analogue = candidates tried per position: 1-2: none (offset-1 runs only), 3-4: 1, 5-6: 2 (default 5,
+        the reference's setting), 7: 4, 8: 8, 9: 16"""
         check(self.lib.hhgt_set_clevel(self.h, int(clevel)))
 
     # ---- codec ---------------------------------------------------------------------------------

@@ -173,15 +173,19 @@ int hhgt_pad_tail_cursor(hhgt_ctx *ctx, const hhgt_layout *lay, const uint64_t *
  *                  overflow afterwards, so it REQUIRES dst_cap >= hhgt_compress_bound(...) (HHGT_ERR_CAPACITY otherwise).
  * Constraints: 1 <= typesize <= 255; blocksize % typesize == 0; 16 <= blocksize <= 65536 (clamped to the chunk size, as c-blosc does);
  * chunk_nbytes < 2 GiB.
- * The streams are valid LZ4 blocks for any input, but the match search is tuned to this path's data (byte planes of
- * genotype matrices, one-hot rows): minimum match 6, hash context of 12 bytes, offset-1 run candidate (csrc/lz4.hip).
+ * The streams are valid LZ4 blocks for any input, but the match search is tuned to this path's data.  The case the path is
+ * built for — typesize 2, 8 KiB blocks: two 4 KiB byte planes per block, haplotypes of 0 / 1 — is coded from the list of a
+ * plane's ones (csrc/lz4bits.hip); planes with other byte values (missing calls, third alleles), very dense planes and
+ * every other geometry go through the byte-wise coder (csrc/lz4.hip: minimum match 6, 12-byte hash context, offset-1 run
+ * candidate).
  * format: HHGT_BLOSC1 = the 16-byte-header chunk of c-blosc 1.x, what HDF5 filter 32001 stores; HHGT_BLOSC2 = the
  * 32-byte extended header of c-blosc2.
  * ------------------------------------------------------------------------------------------- */
 uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize);
-/* Blosc clevel analogue (the reference passes clevel 5: compression_opts[4], vcf_to_h5.py:135).  3..6 (default 5):
- * hash + run candidates; 1..2: run candidate only (LZ4 "acceleration": faster, lower ratio); 7..9: plus long-run
- * sources, backward extension and full extension of every match (about 40 % slower, ~10 % tighter).  Every level emits the same LZ4 block format. */
+/* Blosc clevel analogue (the reference passes clevel 5: compression_opts[4], vcf_to_h5.py:135) = search effort, candidates
+ * tried per position: 1..2: none (offset-1 runs only), 3..4: 1, 5..6: 2 (default 5), 7: 4, 8: 8, 9: 16; on 1000G-shaped
+ * planes ratio 5.6 / 5.9 / 6.1 / 6.2 / 6.3 for 1 / 2 / 4 / 8 / 16 at about 0.45 ms more per 3 M x 2504 cohort and
+ * candidate.  Every level emits the same LZ4 block format. */
 int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
 /* NON-REFERENCE mode (measured separately and labelled so): with on != 0 the record filter also
  * keeps multi-allelic SNP sites — |REF| = 1 and ALT a comma-separated list of single bases from {A,C,G,T} — where the
