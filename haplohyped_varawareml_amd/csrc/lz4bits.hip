@@ -117,7 +117,10 @@ __device__ __forceinline__ uint32_t bp_gap4(const uint32_t *gbw, uint32_t i)
     return __builtin_amdgcn_alignbit(gbw[w + 1u], gbw[w], (i & 3u) << 3);
 }
 
-__device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return x >= 15u ? (x - 15u) / 255u + 1u : 0u; }
+// extension bytes of an LZ4 length field: x >= 15 ? (x - 15) / 255 + 1 : 0 = (x + 240) / 255 for every x; the division as
+// a 24-bit multiply and a shift (exact below 65536; the compiler's v_mul_hi_u32 runs at a quarter of the rate, and the
+// kernel evaluates this eight times per window)
+__device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return __umul24(x + 240u, 32897u) >> 23; }
 
 // one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off).  OUT is a pointer
 // into the staging area (LDS: ds_write_b8) or, for a window too large for it, into the stream's slot in global memory.
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         u32x4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(p + 64 * k);   // streamed once
-        uint32_t nb0 = 0, nb1 = 0;
+        uint32_t orall = 0;
         uint8_t *bm0 = reinterpret_cast<uint8_t *>(lds[0].bm) + 256u * wave + lane;
         uint8_t *bm1 = reinterpret_cast<uint8_t *>(lds[1].bm) + 256u * wave + lane;
 #pragma unroll
@@ -216,8 +219,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t x = d[i];
-                nb0 |= x & 0x00FE00FEu;
-                nb1 |= x & 0xFE00FE00u;
+                orall |= x;
                 const uint32_t xm = x & 0x01010101u;   // (a byte > 1 in one plane must not leak into the other plane's bits)
                 const uint32_t y = xm | (xm >> 15);    // bits 0,1: plane-0 bytes; bits 8,9: plane-1 bytes
                 acc0 |= (y & 3u) << (2 * i);
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             bm0[64 * k] = (uint8_t)acc0;
             bm1[64 * k] = (uint8_t)acc1;
         }
+        const uint32_t nb0 = orall & 0x00FE00FEu, nb1 = orall & 0xFE00FE00u;   // a byte > 1 somewhere in plane 0 / plane 1
         const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nb0 != 0u), b1 = __builtin_amdgcn_ballot_w64(nb1 != 0u);
         if (lane == 0) {
             nonbin[wave][0] = b0 != 0ull;
