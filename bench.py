@@ -518,7 +518,7 @@ def main():
     if dom == "lz4":
         # the contract's roofline is HBM or MFMA; this kernel is bound by neither
         sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_lz4_sq.txt")))
-        roof["limiter"] = ("vector-instruction issue and LDS round trips: ~2.0 k vector + 0.8 k scalar + 0.24 k LDS instructions "
+        roof["limiter"] = ("vector-instruction issue and LDS round trips: ~1.9 k vector + 0.7 k scalar + 0.25 k LDS instructions "
                            "per 4 KiB plane at 7 waves per SIMD (" + (os.path.basename(sq[-1]) if sq else "profiles/") +
                            ", SQ counters from a separate --pmc pass); HBM at a sixth of its peak under this kernel")
 
