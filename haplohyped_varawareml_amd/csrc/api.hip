@@ -1,6 +1,7 @@
 // api.hip — C ABI of libhhgt.so (see include/hhgt.h): context, orchestration of the kernel stages,
 // error reporting.  No CPU fallback anywhere: every compute entry point needs a HIP device.
 #include "common.h"
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -712,6 +713,48 @@ extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)
         return HHGT_ERR_ARG;
     }
     c->clevel = clevel;
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_stream_create(hhgt_ctx *c, int kind, void **out)
+{
+    if (!c || !out || (kind != HHGT_STREAM_ENCODE && kind != HHGT_STREAM_COMPRESS)) {
+        hhgt_set_error("hhgt_stream_create: bad arguments");
+        return HHGT_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = nullptr;
+    if (kind == HHGT_STREAM_ENCODE) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+    } else {
+        const uint32_t n_cu = (uint32_t)c->prop.multiProcessorCount;
+        // the mask works in groups of 32 CUs on this part (one XCD): 3/4 of the chip, rounded to that
+        uint32_t use = n_cu >= 128u ? (n_cu * 3u / 4u) / 32u * 32u : n_cu;
+        if (const char *e = getenv("HHGT_COMPRESS_CUS")) {
+            const int v = atoi(e);
+            use = v <= 0 || (uint32_t)v >= n_cu ? n_cu : (uint32_t)v;
+        }
+        if (use >= n_cu) {
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        } else {
+            std::vector<uint32_t> mask((n_cu + 31u) / 32u, 0u);
+            for (uint32_t i = n_cu - use; i < n_cu; ++i) mask[i >> 5] |= 1u << (i & 31u);   // the last `use` CUs of the mask order
+            HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+        }
+    }
+    *out = st;
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_stream_destroy(hhgt_ctx *c, void *stream)
+{
+    if (!c) return HHGT_ERR_ARG;
+    if (stream) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    }
     return HHGT_OK;
 }
 

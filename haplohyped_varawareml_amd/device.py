@@ -130,6 +130,9 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for st in getattr(self, "_streams", []):
+                self.lib.hhgt_stream_destroy(self.h, st)
+            self._streams = []
             self.lib.hhgt_ctx_destroy(self.h)
             self.h = None
 
@@ -207,6 +210,16 @@ class Context:
         with torch.cuda.device(self.device):
             check(self.lib.hhgt_pad_tail(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end),
                                          _ptr(res.G), _stream()))
+
+    def create_stream(self, kind):
+        """kind "encode" | "compress": the stream pair for running compress of one block beside encode of the next
+        (include/hhgt.h hhgt_stream_create: the compress stream is restricted to 3/4 of the CUs) -> torch ExternalStream,
+        destroyed with the context"""
+        h = C.c_void_p()
+        check(self.lib.hhgt_stream_create(self.h, {"encode": 0, "compress": 1}[kind], C.byref(h)))
+        self._streams = getattr(self, "_streams", [])
+        self._streams.append(h)
+        return torch.cuda.ExternalStream(h.value, device=self.device)
 
     def set_keep_multiallelic(self, on=True):
         """NON-REFERENCE mode: multi-allelic SNP sites pass the record filter (the reference's isSNP drops them);

@@ -275,7 +275,23 @@ int hhgt_inflate_members(hhgt_ctx *ctx, const void *d_src, uint64_t src_bytes, c
 #define HHGT_STAGE_FRAME 5    /* Blosc2 framing / compaction                                     */
 #define HHGT_STAGE_DECODE 6   /* chunk decode                                                    */
 #define HHGT_STAGE_ONEHOT 7   /* one-hot haplotype windows                                       */
-#define HHGT_STAGE_INFLATE 8  /* BGZF members inflated on the device                            */
+#define HHGT_STAGE_INFLATE 8  /* Streams for callers that run hhgt_compress_chunks of one block BESIDE hhgt_encode_text_async of the next (two
+ * streams, events in between; what bench.py does).  Both are plain hipStream_t values, usable wherever this header takes
+ * `void *stream`.
+ *   HHGT_STREAM_ENCODE    high priority, every CU
+ *   HHGT_STREAM_COMPRESS  default priority, restricted (hipExtStreamCreateWithCUMask) to 3/4 of the CUs: the LZ4 kernel
+ *                         is bound by instruction issue and fills every CU it may use with resident waves, and the
+ *                         encode chain of the next block — two HBM-bound passes with latency-bound small kernels in
+ *                         between — then waits for slots one workgroup at a time (k_parse_fixed: 146 us beside LZ4, 40 us
+ *                         alone).  With a quarter of the chip kept free of LZ4 the step of the 3 M x 2504 cohort takes
+ *                         24.9 instead of 26.3 ms.  HHGT_COMPRESS_CUS=n overrides the CU count (0 = all).
+ * Destroy with hhgt_stream_destroy before hhgt_ctx_destroy. */
+#define HHGT_STREAM_ENCODE 0
+#define HHGT_STREAM_COMPRESS 1
+int hhgt_stream_create(hhgt_ctx *ctx, int kind, void **stream);
+int hhgt_stream_destroy(hhgt_ctx *ctx, void *stream);
+
+/* BGZF members inflated on the device                            */
 #define HHGT_N_STAGES 9
 int hhgt_profile_enable(hhgt_ctx *ctx, int on);
 int hhgt_profile_reset(hhgt_ctx *ctx);

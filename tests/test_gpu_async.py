@@ -152,3 +152,27 @@ def test_compress_async_needs_the_bound(ctx):
         ctx.compress(src, 65536, dst=small, sync=False)
     dst, off, total = ctx.compress(src, 65536, dst=small, sync=True)      # the synchronous form sizes exactly
     assert total <= 4000
+
+
+def test_stream_pair_helpers(ctx):
+    """hhgt_stream_create: the encode / compress stream pair (the compress stream carries a CU mask) runs the same
+    kernels to the same bytes as the default stream"""
+    from haplohyped_varawareml_amd import synth
+    S, V = 200, 9000
+    tab = synth.variant_table(9, V, S)
+    text, _ = ctx.synth_fixed("chr9", tab, S, seed=9)
+    lay = dev.make_layout(S, V)
+    ref = ctx.encode_text(text, S, region="chr9", layout=lay)
+    ctx.pad_tail(ref)
+    chunk = lay.sc * lay.vc * 2
+    d0, o0, t0 = ctx.compress(ref.G, chunk)
+    s_enc, s_cmp = ctx.create_stream("encode"), ctx.create_stream("compress")
+    with torch.cuda.stream(s_enc):
+        res = ctx.encode_text(text, S, region="chr9", layout=lay)
+        ctx.pad_tail(res)
+        done = s_enc.record_event()
+    with torch.cuda.stream(s_cmp):
+        s_cmp.wait_event(done)
+        d1, o1, t1 = ctx.compress(res.G, chunk)
+    torch.cuda.synchronize()
+    assert t1 == t0 and torch.equal(o0, o1) and torch.equal(d0[:t0], d1[:t1]) and torch.equal(ref.G, res.G)
