@@ -741,7 +741,11 @@ extern "C" int hhgt_stream_create(hhgt_ctx *c, int kind, void **out)
         } else {
             std::vector<uint32_t> mask((n_cu + 31u) / 32u, 0u);
             for (uint32_t i = n_cu - use; i < n_cu; ++i) mask[i >> 5] |= 1u << (i & 31u);   // the last `use` CUs of the mask order
-            HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+            if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();   // a runtime that refuses the mask: an ordinary stream does the same work
+                st = nullptr;
+                HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            }
         }
     }
     *out = st;
