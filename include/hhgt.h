@@ -284,7 +284,7 @@ int hhgt_inflate_members(hhgt_ctx *ctx, const void *d_src, uint64_t src_bytes, c
  *                         encode chain of the next block — two HBM-bound passes with latency-bound small kernels in
  *                         between — then waits for slots one workgroup at a time (k_parse_fixed: 146 us beside LZ4, 40 us
  *                         alone).  With a quarter of the chip kept free of LZ4 the step of the 3 M x 2504 cohort takes
- *                         24.9 instead of 26.3 ms.  HHGT_COMPRESS_CUS=n overrides the CU count (0 = all).
+ *                         24.7-25.3 instead of 26.3 ms.  HHGT_COMPRESS_CUS=n overrides the CU count (0 = all).
  * Destroy with hhgt_stream_destroy before hhgt_ctx_destroy. */
 #define HHGT_STREAM_ENCODE 0
 #define HHGT_STREAM_COMPRESS 1
