@@ -388,12 +388,11 @@ static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, 
                                c->l_cnew.as<uint32_t>(), cnt, st));
         TRY(launch_scan_exclusive_u32_pair(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), c->l_cnew.as<uint32_t>(),
                                            c->l_crun.as<uint32_t>(), max_lines, c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
-        HIP_TRY(hipMemsetAsync(c->redo_flag.p, 0, (size_t)max_lines * 4, st));
         TRY(launch_compact_kept(text, nbytes, c->nl.as<uint32_t>(), d_nlines, max_lines, c->l_soff.as<uint32_t>(),
                                 c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(), c->l_refalt.as<uint32_t>(),
                                 c->l_flags.as<uint32_t>(), c->l_kidx.as<uint32_t>(), c->l_crun.as<uint32_t>(),
                                 c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(), c->k_meta.as<uint32_t>(),
-                                c->redo_list.as<uint32_t>(), c->run_first.as<uint64_t>(), c->run_names.as<uint8_t>(),
+                                c->redo_list.as<uint32_t>(), c->redo_flag.as<uint32_t>(), c->run_first.as<uint64_t>(), c->run_names.as<uint8_t>(),
                                 MAX_CHROM_RUNS, d_cursor, L.v_capacity, L.ring, d_start, d_stop, d_ref, d_alt, cnt, st));
         t.stop();
     }

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     const uint32_t *__restrict__ l_lend, const uint32_t *__restrict__ l_pos, const uint32_t *__restrict__ l_refalt,
     const uint32_t *__restrict__ l_flags, const uint32_t *__restrict__ l_kidx, const uint32_t *__restrict__ l_crun,
     uint32_t *__restrict__ k_soff, uint32_t *__restrict__ k_lend, uint32_t *__restrict__ k_meta,
-    uint32_t *__restrict__ redo_list, uint64_t *__restrict__ run_first, uint8_t *__restrict__ run_names,
+    uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag, uint64_t *__restrict__ run_first, uint8_t *__restrict__ run_names,
     uint32_t max_runs, const uint64_t *__restrict__ d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *__restrict__ d_start,
     uint32_t *__restrict__ d_stop, uint8_t *__restrict__ d_ref, uint8_t *__restrict__ d_alt, DevCounters *cnt)
 {
@@ -461,6 +461,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     k_soff[k] = l_soff[i];
     k_lend[k] = l_lend[i];
     k_meta[k] = (flags & LF_FAST) | ((ra >> 16) << 8);  // bit2 = FAST, bits 8.. = GT key index
+    redo_flag[k] = 0u;                                  // (the tile kernel's "line already queued for the general path" mark)
     if (!(flags & LF_FAST)) {
         unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
         redo_list[slot] = k;
@@ -529,13 +530,13 @@ int launch_compact_kept(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl,
                         const uint32_t *l_soff, const uint32_t *l_lend,
                         const uint32_t *l_pos, const uint32_t *l_refalt, const uint32_t *l_flags,
                         const uint32_t *l_kidx, const uint32_t *l_crun, uint32_t *k_soff, uint32_t *k_lend,
-                        uint32_t *k_meta, uint32_t *redo_list, uint64_t *run_first, uint8_t *run_names,
+                        uint32_t *k_meta, uint32_t *redo_list, uint32_t *redo_flag, uint64_t *run_first, uint8_t *run_names,
                         uint32_t max_runs, const uint64_t *d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *d_start,
                         uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, hipStream_t st)
 {
     if (max_lines == 0) return HHGT_OK;
     hipLaunchKernelGGL(k_compact_kept, dim3((max_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, d_nlines, max_lines,
-                       l_soff, l_lend, l_pos, l_refalt, l_flags, l_kidx, l_crun, k_soff, k_lend, k_meta, redo_list,
+                       l_soff, l_lend, l_pos, l_refalt, l_flags, l_kidx, l_crun, k_soff, k_lend, k_meta, redo_list, redo_flag,
                        run_first, run_names, max_runs, d_cursor, v_capacity, ring, d_start, d_stop, d_ref, d_alt, d_cnt);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
