@@ -88,6 +88,14 @@ def load():
                                    C.POINTER(EncodeStats), vp]
     L.hhgt_encode_text_async.argtypes = [vp, vp, u64, C.c_char_p, C.POINTER(Layout), vp, C.c_uint32, vp, vp, vp, vp, vp,
                                          vp, vp]
+    L.hhgt_planes_bytes.restype = u64
+    L.hhgt_planes_bytes.argtypes = [C.POINTER(Layout)]
+    L.hhgt_encode_text_planes_async.argtypes = [vp, vp, u64, C.c_char_p, C.POINTER(Layout), vp, C.c_uint32, vp, vp, vp, vp, vp, vp,
+                                                vp, vp]
+    L.hhgt_pad_tail_planes_cursor.argtypes = [vp, C.POINTER(Layout), vp, vp, vp]
+    L.hhgt_pad_tail_planes.argtypes = [vp, C.POINTER(Layout), u64, u64, u64, vp, vp]
+    L.hhgt_compress_planes.argtypes = [vp, vp, vp, u64, u64, i32, vp, u64, vp, C.POINTER(u64), vp]
+    L.hhgt_planes_expand.argtypes = [vp, vp, vp, u64, vp, vp]
     L.hhgt_encode_result_status.argtypes = [vp]
     L.hhgt_pad_tail_cursor.argtypes = [vp, C.POINTER(Layout), vp, vp, vp]
     L.hhgt_encode_chrom_runs.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(C.c_uint32)]

@@ -311,7 +311,7 @@ __global__ void k_encode_finish(DevCounters *cnt, uint64_t *cursor, const uint64
         res->err_density = cnt->err_density;
         res->v_capacity = v_capacity;
         res->done = 1u;
-        res->reserved = 0u;
+        res->reserved = cnt->n_other > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt->n_other;   // bit-plane form: calls beyond 0 / 1 / missing
     }
     const uint64_t n_runs = cnt->n_chrom_runs;
     if (t < HHGT_RESULT_RUNS) res->run_first[t] = t < n_runs ? run_first[t] : 0ull;
@@ -360,7 +360,7 @@ static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes,
 
 // stages 2..: everything behind the index, sized by max_lines, counts and append position read on the device
 static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, uint32_t max_lines,
-                             const RegionFilter &rf, const LayoutDev &L, const uint64_t *d_cursor, void *d_G, uint32_t *d_start, uint32_t *d_stop,
+                             const RegionFilter &rf, const LayoutDev &L, const uint64_t *d_cursor, void *d_G, void *d_P, uint32_t *d_start, uint32_t *d_stop,
                              uint8_t *d_ref, uint8_t *d_alt, DevCounters *cnt, hipStream_t st)
 {
     const uint32_t *d_nlines = c->prefix.as<uint32_t>() + n_regions;
@@ -398,14 +398,19 @@ static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, 
     }
     if (L.S > 0) {
         StageTimer t(c, st, HHGT_STAGE_ENCODE);
-        TRY(launch_encode_tiles(text, nbytes, c->k_soff.as<uint32_t>(), c->k_meta.as<uint32_t>(), max_lines, d_cursor,
-                                L, static_cast<int8_t *>(d_G), c->redo_list.as<uint32_t>(),
-                                c->redo_flag.as<uint32_t>(), cnt, st));
+        if (d_P)
+            TRY(launch_encode_planes(text, nbytes, c->k_soff.as<uint32_t>(), c->k_meta.as<uint32_t>(), max_lines, d_cursor, L,
+                                     static_cast<uint8_t *>(d_P), static_cast<int8_t *>(d_G), c->redo_list.as<uint32_t>(),
+                                     c->redo_flag.as<uint32_t>(), cnt, st));
+        else
+            TRY(launch_encode_tiles(text, nbytes, c->k_soff.as<uint32_t>(), c->k_meta.as<uint32_t>(), max_lines, d_cursor,
+                                    L, static_cast<int8_t *>(d_G), c->redo_list.as<uint32_t>(),
+                                    c->redo_flag.as<uint32_t>(), cnt, st));
         t.stop();
         StageTimer t2(c, st, HHGT_STAGE_GENERAL);
         TRY(launch_encode_general(text, nbytes, c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(),
                                   c->k_meta.as<uint32_t>(), c->redo_list.as<uint32_t>(), d_cursor, L,
-                                  static_cast<int8_t *>(d_G), cnt, c->prop.multiProcessorCount, st));
+                                  static_cast<int8_t *>(d_G), static_cast<uint8_t *>(d_P), cnt, c->prop.multiProcessorCount, st));
         t2.stop();
     }
     return HHGT_OK;
@@ -462,17 +467,34 @@ static void empty_result(hhgt_encode_result *r)
     r->done = 1u;
 }
 
-extern "C" int hhgt_encode_text_async(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
-                                      const hhgt_layout *lay, uint64_t *d_cursor, uint32_t max_lines, void *d_G,
-                                      uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt,
-                                      hhgt_encode_result *h_result, void *stream)
+// a layout can carry bit planes when a Blosc block (4096 variants of one sample) never crosses a chunk column
+static int planes_check_layout(const LayoutDev &L)
+{
+    if (L.Vc % 4096ull) {
+        hhgt_set_error("planes: variants per chunk (%llu; dense: v_capacity) must be a multiple of 4096", (unsigned long long)L.Vc);
+        return HHGT_ERR_ARG;
+    }
+    return HHGT_OK;
+}
+
+extern "C" uint64_t hhgt_planes_bytes(const hhgt_layout *lay)
+{
+    LayoutDev L;
+    if (make_layout(lay, &L) != HHGT_OK || planes_check_layout(L) != HHGT_OK) return 0;
+    return (uint64_t)L.n_sc * L.Sc * L.v_capacity / 2ull;
+}
+
+static int encode_async_impl(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region, const hhgt_layout *lay,
+                             uint64_t *d_cursor, uint32_t max_lines, void *d_G, void *d_P, bool planes, uint32_t *d_start,
+                             uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_result *h_result, void *stream)
 {
     if (!c || !d_cursor) return HHGT_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
     LayoutDev L;
     RegionFilter rf;
-    TRY(encode_check_args(c, d_text, nbytes, lay, &L, region, &rf, d_G));
+    TRY(encode_check_args(c, d_text, nbytes, lay, &L, region, &rf, planes ? d_P : d_G));
+    if (planes) TRY(planes_check_layout(L));
     const uint8_t *text = static_cast<const uint8_t *>(d_text);
     DevCounters *cnt = c->counters.as<DevCounters>();
     HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));
@@ -483,7 +505,8 @@ extern "C" int hhgt_encode_text_async(hhgt_ctx *c, const void *d_text, uint64_t 
             TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, cnt, st));
             t.stop();
         }
-        TRY(encode_stage_rest(c, text, nbytes, n_regions, max_lines, rf, L, d_cursor, d_G, d_start, d_stop, d_ref, d_alt, cnt, st));
+        TRY(encode_stage_rest(c, text, nbytes, n_regions, max_lines, rf, L, d_cursor, d_G, planes ? d_P : nullptr, d_start, d_stop, d_ref,
+                              d_alt, cnt, st));
     }
     TRY(encode_finish(c, d_cursor, L, cnt, st));
     if (h_result) {
@@ -491,6 +514,58 @@ extern "C" int hhgt_encode_text_async(hhgt_ctx *c, const void *d_text, uint64_t 
         HIP_TRY(hipMemcpyAsync(h_result, c->result.p, sizeof(hhgt_encode_result), hipMemcpyDeviceToHost, st));
     }
     return HHGT_OK;
+}
+
+extern "C" int hhgt_encode_text_async(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
+                                      const hhgt_layout *lay, uint64_t *d_cursor, uint32_t max_lines, void *d_G,
+                                      uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt,
+                                      hhgt_encode_result *h_result, void *stream)
+{
+    return encode_async_impl(c, d_text, nbytes, region, lay, d_cursor, max_lines, d_G, nullptr, false, d_start, d_stop, d_ref, d_alt,
+                             h_result, stream);
+}
+
+extern "C" int hhgt_encode_text_planes_async(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
+                                             const hhgt_layout *lay, uint64_t *d_cursor, uint32_t max_lines, void *d_P, void *d_G,
+                                             uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt,
+                                             hhgt_encode_result *h_result, void *stream)
+{
+    return encode_async_impl(c, d_text, nbytes, region, lay, d_cursor, max_lines, d_G, d_P, true, d_start, d_stop, d_ref, d_alt,
+                             h_result, stream);
+}
+
+extern "C" int hhgt_pad_tail_planes(hhgt_ctx *c, const hhgt_layout *lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end,
+                                    void *d_P, void *stream)
+{
+    if (!c || !d_P) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    LayoutDev L;
+    TRY(make_layout(lay, &L));
+    TRY(planes_check_layout(L));
+    if (v_end > L.v_capacity || vcol_end > L.v_capacity / L.Vc) {
+        hhgt_set_error("pad_tail: range outside the layout");
+        return HHGT_ERR_ARG;
+    }
+    return launch_pad_tail_planes(L, v_end, vcol_begin, vcol_end, static_cast<uint8_t *>(d_P), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int hhgt_pad_tail_planes_cursor(hhgt_ctx *c, const hhgt_layout *lay, const uint64_t *d_cursor, void *d_P, void *stream)
+{
+    if (!c || !d_P || !d_cursor) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    LayoutDev L;
+    TRY(make_layout(lay, &L));
+    TRY(planes_check_layout(L));
+    return launch_pad_tail_planes_cursor(L, d_cursor, static_cast<uint8_t *>(d_P), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int hhgt_planes_expand(hhgt_ctx *c, const void *d_P, const void *d_G, uint64_t n_blocks, void *d_out, void *stream)
+{
+    if (!c || !d_P || !d_out) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_blocks == 0) return HHGT_OK;
+    return launch_planes_expand(static_cast<const uint8_t *>(d_P), static_cast<const uint8_t *>(d_G), n_blocks,
+                                static_cast<uint8_t *>(d_out), reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
@@ -537,7 +612,7 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
     }
     if (stats) stats->n_lines = n_lines;
     if (n_lines == 0) return HHGT_OK;
-    TRY(encode_stage_rest(c, text, nbytes, n_regions, n_lines, rf, L, c->cursor.as<uint64_t>(), d_G, d_start, d_stop, d_ref,
+    TRY(encode_stage_rest(c, text, nbytes, n_regions, n_lines, rf, L, c->cursor.as<uint64_t>(), d_G, nullptr, d_start, d_stop, d_ref,
                           d_alt, cnt, st));
     TRY(encode_finish(c, c->cursor.as<uint64_t>(), L, cnt, st));
     hhgt_encode_result *hr = &c->h_result;
@@ -649,11 +724,13 @@ extern "C" uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes
     return n_chunks * (chunk_nbytes + 32);
 }
 
-extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
-                                    int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
-                                    uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream)
+// shuffle + LZ4 + framing of n_chunks chunks that exist as int8 bytes (d_src) or as bit planes (d_planes; d_src then only
+// holds the bytes of calls beyond 0 / 1 / missing and may be NULL)
+static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, uint64_t n_chunks, uint64_t chunk_nbytes,
+                         int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
+                         uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream)
 {
-    if (!c || !d_src || !d_dst || !d_chunk_off) return HHGT_ERR_ARG;
+    if (!c || (!d_src && !d_planes) || !d_dst || !d_chunk_off) return HHGT_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
     TRY(check_codec_args(chunk_nbytes, typesize, blocksize, format));
@@ -678,16 +755,16 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
     TRY(c->fr_flags.ensure((size_t)n_chunks * 4));
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
-        TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize,
-                              c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel, c->lz_marked.as<uint32_t>() + 1,
-                              c->lz_marked.as<uint32_t>(), st));
+        TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), n_chunks, chunk_nbytes, typesize,
+                              blocksize, c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel,
+                              c->lz_marked.as<uint32_t>() + 1, c->lz_marked.as<uint32_t>(), st));
         t.stop();
     }
     {
         StageTimer t(c, st, HHGT_STAGE_FRAME);
         TRY(launch_frame(c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(),
-                         static_cast<const uint8_t *>(d_src), n_chunks, chunk_nbytes, typesize, blocksize, format,
-                         c->fr_bsize.as<uint32_t>(), c->fr_csize.as<uint64_t>(), static_cast<uint8_t *>(d_dst),
+                         static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), n_chunks, chunk_nbytes, typesize,
+                         blocksize, format, c->fr_bsize.as<uint32_t>(), c->fr_csize.as<uint64_t>(), static_cast<uint8_t *>(d_dst),
                          dst_cap, d_chunk_off, c->fr_flags.as<uint32_t>(), st));
         t.stop();
     }
@@ -703,6 +780,27 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
         }
     }
     return HHGT_OK;
+}
+
+extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
+                                    int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
+                                    uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream)
+{
+    if (!d_src) return HHGT_ERR_ARG;
+    return compress_impl(c, d_src, nullptr, n_chunks, chunk_nbytes, typesize, blocksize, format, d_dst, dst_cap, d_chunk_off,
+                         total_bytes, stream);
+}
+
+extern "C" int hhgt_compress_planes(hhgt_ctx *c, const void *d_P, const void *d_G, uint64_t n_chunks, uint64_t chunk_nbytes,
+                                    int format, void *d_dst, uint64_t dst_cap, uint64_t *d_chunk_off, uint64_t *total_bytes,
+                                    void *stream)
+{
+    if (!d_P) return HHGT_ERR_ARG;
+    if (chunk_nbytes % 8192ull) {
+        hhgt_set_error("compress_planes: chunk_nbytes (%llu) must be a multiple of the 8192-byte block", (unsigned long long)chunk_nbytes);
+        return HHGT_ERR_ARG;
+    }
+    return compress_impl(c, d_G, d_P, n_chunks, chunk_nbytes, 2, 8192, format, d_dst, dst_cap, d_chunk_off, total_bytes, stream);
 }
 
 extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)

@@ -46,7 +46,8 @@ struct DevCounters {
     unsigned long long err_density;  // newline-slot overflow
     unsigned long long err_lines;    // lines beyond the caller's max_lines (asynchronous form only)
     unsigned long long cursor_after; // *d_cursor after the call
-    unsigned long long pad[4];
+    unsigned long long n_other;      // bit-plane form: calls that are neither 0, 1 nor missing (their bytes went to d_G)
+    unsigned long long pad[3];
 };
 
 #define MAX_CHROM_RUNS 4096u
@@ -163,7 +164,14 @@ int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_sof
                         uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st);
 int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_lend,
                           const uint32_t *k_meta, const uint32_t *redo_list, const uint64_t *d_cursor, LayoutDev lay,
-                          int8_t *d_G, DevCounters *d_cnt, int n_cu, hipStream_t st);
+                          int8_t *d_G, uint8_t *d_P, DevCounters *d_cnt, int n_cu, hipStream_t st);
+// bit-plane form of the matrix (include/hhgt.h): 2048 plane bytes per 8 KiB block of G
+int launch_encode_planes(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_meta,
+                         uint32_t n_lines_bound, const uint64_t *d_cursor, LayoutDev lay, uint8_t *d_P, int8_t *d_G,
+                         uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st);
+int launch_pad_tail_planes(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, uint8_t *d_P, hipStream_t st);
+int launch_pad_tail_planes_cursor(LayoutDev lay, const uint64_t *d_cursor, uint8_t *d_P, hipStream_t st);
+int launch_planes_expand(const uint8_t *d_P, const uint8_t *d_G, uint64_t n_blocks, uint8_t *d_out, hipStream_t st);
 int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, int8_t *d_G,
                     hipStream_t st);
 // zero [*d_cursor, round_up(*d_cursor, Vc)) of the cursor's chunk column and the sample padding rows of that column
@@ -171,14 +179,16 @@ int launch_pad_tail_cursor(LayoutDev lay, const uint64_t *d_cursor, int8_t *d_G,
 
 // lz4.hip
 size_t lz4_slot_bytes(int neblock);
-int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+// d_planes != NULL: the chunks exist as bit planes (hhgt.h "Bit-plane form"); d_src then only supplies the bytes of calls
+// beyond 0 / 1 / missing and may be NULL
+int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
                       int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
                       uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st);
 // lz4bits.hip: typesize 2, 8 KiB blocks; streams it cannot code get csize = 0xFFFFFFFF
-int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
                          uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st);
 // frame.hip
-int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src,
+int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
                  uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
                  uint32_t *d_bstart, uint64_t *d_chunk_csize, uint8_t *d_dst, uint64_t dst_cap,
                  uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st);

@@ -188,6 +188,255 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 }
 
 // -------------------------------------------------------------------------------------------------
+// k_encode_planes: the same pass as k_encode_tiles for callers whose only consumer of the matrix is the compressor —
+// two BITS per allele instead of a byte (include/hhgt.h "Bit-plane form"): ONE (allele 1, or missing) and EXC (anything
+// but 0 / 1), so what crosses HBM between the two halves of the path is S/2 bytes per variant each way instead of 2 S.
+//
+// A 256-thread workgroup owns 512 variants x 256 samples: 512 variants so that every (sample, plane) leaves as 64
+// contiguous bytes; wave w reads lines [128 w, 128 w + 128) of the tile, 8 lines (1 KiB each, 16 B per lane = 4
+// samples) in flight while the previous 8 are packed.  Packing is SWAR on the field dword "a|b\t": (x & 0x00010001)
+// holds the two allele bits, shifted by the line number they accumulate into a register whose low half is haplotype 0
+// and whose high half is haplotype 1 over 16 lines; one xor/or chain per line tells whether all four fields of the lane
+// were "[01]|[01]\t".  Only a group of 16 lines in which some lane saw anything else (a missing call, '/', a third
+// allele) is parsed again field by field.  Per 32 lines a lane holds one dword per (sample, plane, kind): 16
+// conflict-free ds_write_b32 into a 64 KiB image [kind][plane][sample][64 B]; after one barrier the image leaves in
+// 16-byte pieces, four lanes per 64-byte row.  The tile that straddles the append position merges with the bits the
+// previous call wrote.
+// HBM roofline: algorithmic bytes per variant = 4 S read + S/2 written.
+#define PT_V 512
+#define PT_LW 128
+#define PT_G 8
+#define PT_C 0x09307C30u   // "0|0\t"
+
+struct PlGroup {
+    uint4 raw[PT_G];
+    uint32_t lvalid;   // bit j: line j of the group is a kept fixed-width line (wave-uniform)
+};
+
+template <bool EDGE>
+__device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__restrict__ text, uint64_t n,
+                                              const uint32_t *__restrict__ k_soff, const uint32_t *__restrict__ k_meta,
+                                              long long kbase, uint32_t n_kept, uint32_t ls, uint32_t nval, uint32_t last_q)
+{
+    uint32_t lv = 0;
+#pragma unroll
+    for (int j = 0; j < PT_G; ++j) {
+        const long long k = kbase + j;
+        bool valid = k >= 0 && k < (long long)n_kept;
+        uint32_t meta = 0, soff = 0;
+        if (valid) {
+            meta = k_meta[k];
+            soff = k_soff[k];
+        }
+        valid = valid && (meta & LF_FAST);
+        uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
+        if (valid) {
+            lv |= 1u << j;
+            const uint64_t off = (uint64_t)soff + 4ull * ls;
+            if (!EDGE) {   // every lane owns four samples in front of the line's last one: the 16 bytes lie inside the line
+                u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            } else if (nval == 4u && off + 16ull <= n) {
+                u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            } else if (nval) {
+                uint32_t d[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t x = FILL_FIELD;
+                    if ((uint32_t)q < nval) {
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            uint64_t idx = off + (uint64_t)(q * 4 + bb);
+                            uint32_t c = idx < n ? text[idx] : (uint32_t)'\t';
+                            x = (x & ~(0xFFu << (bb * 8))) | (c << (bb * 8));
+                        }
+                    }
+                    d[q] = x;
+                }
+                v = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            if (EDGE) {   // the last sample of a line is terminated by the line end (LF_FAST pinned where it ends)
+                if (last_q == 0u) v.x = (v.x & 0x00FFFFFFu) | 0x09000000u;
+                if (last_q == 1u) v.y = (v.y & 0x00FFFFFFu) | 0x09000000u;
+                if (last_q == 2u) v.z = (v.z & 0x00FFFFFFu) | 0x09000000u;
+                if (last_q == 3u) v.w = (v.w & 0x00FFFFFFu) | 0x09000000u;
+            }
+        }
+        gr.raw[j] = v;
+    }
+    gr.lvalid = lv;
+}
+
+// 16 lines -> per sample q: one[q] / exc[q], bit j (haplotype 0) and bit 16 + j (haplotype 1) for line j.
+// Three levels.  (1) every field of every lane is "[01]|[01]\t": 14 vector instructions per line.  (2) some lane saw
+// something else: the group again with every field classified over the alphabet {0, 1, .} x {|, /} — still branch-free
+// SWAR on the field dword, x ^ "0|0\t": an allele byte must be 0x00, 0x01 or 0x1E ('.'), bit 4 of it is the EXC bit and
+// bit 0 | bit 4 the ONE bit; the separator byte 0x00 or 0x53 ('/'), the terminator 0x00.  (3) a field outside that
+// alphabet (a third allele, a multi-digit index, anything malformed) contributes zero bits and sends its line to the
+// variable-width kernel, which sets the bits of the whole line (idempotent for the fields that were fine here).
+__device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, uint32_t (&one)[4], uint32_t (&exc)[4], long long kbase,
+                                              uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag, DevCounters *cnt,
+                                              uint32_t lane)
+{
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, bad = 0;
+#pragma unroll
+    for (int j = 0; j < PT_G; ++j) {
+        const uint4 x = gr.raw[j];
+        a0 |= (x.x & 0x00010001u) << (sh + j);
+        a1 |= (x.y & 0x00010001u) << (sh + j);
+        a2 |= (x.z & 0x00010001u) << (sh + j);
+        a3 |= (x.w & 0x00010001u) << (sh + j);
+        bad |= ((x.x ^ PT_C) | (x.y ^ PT_C)) | ((x.z ^ PT_C) | (x.w ^ PT_C));
+    }
+    if (__builtin_amdgcn_ballot_w64((bad & 0xFFFEFFFEu) != 0u) == 0ull) {
+        one[0] |= a0, one[1] |= a1, one[2] |= a2, one[3] |= a3;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < PT_G; ++j) {
+        const uint32_t xs[4] = {gr.raw[j].x, gr.raw[j].y, gr.raw[j].z, gr.raw[j].w};
+        uint32_t hard = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t y = xs[q] ^ PT_C;
+            const uint32_t t4 = y >> 4;
+            const uint32_t e2 = t4 & 0x00010001u;                                   // '.' in either allele
+            const uint32_t o2 = (y | t4) & 0x00010001u;                             // '1' or '.'
+            const uint32_t want = __umul24(e2, 30u) | (y & 0x00010001u & ~e2);      // what the allele bytes must then be
+            const uint32_t z = y & 0xFF00FF00u, zz = z ^ 0x00005300u;               // separator / terminator bytes
+            const uint32_t off = ((y & 0x00FF00FFu) ^ want) | (z < zz ? z : zz);
+            const uint32_t keep = off ? 0u : 0xFFFFFFFFu;
+            one[q] |= (o2 & keep) << (sh + j);
+            exc[q] |= (e2 & keep) << (sh + j);
+            hard |= off;
+        }
+        if ((gr.lvalid >> j) & 1u) {
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(hard != 0u);
+            if (bm != 0ull && lane == 0) {
+                const uint32_t k = (uint32_t)(kbase + j);
+                if (atomicExch(&redo_flag[k], 1u) == 0u) {
+                    unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
+                    redo_list[slot] = k;
+                }
+            }
+        }
+    }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ k_soff,
+                                                   const uint32_t *__restrict__ k_meta, uint64_t v_base, uint32_t n_kept,
+                                                   const LayoutDev &lay, uint8_t *__restrict__ P, int8_t *__restrict__ G,
+                                                   uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
+                                                   DevCounters *cnt, uint32_t *img)
+{
+    const uint64_t gv0 = (v_base / PT_V + blockIdx.x) * (uint64_t)PT_V;   // first global column of the tile
+    const long long k0 = (long long)gv0 - (long long)v_base;              // batch-local kept index of it
+    if (k0 >= (long long)n_kept || (!lay.ring && gv0 >= lay.v_capacity)) return;
+    const uint32_t s0 = blockIdx.y * TILE_S;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t S = lay.S;
+    const uint32_t ls = s0 + 4u * lane;
+    const uint32_t nval = ls >= S ? 0u : (S - ls >= 4u ? 4u : S - ls);
+    const uint32_t last_q = (S - 1u >= ls && S - 1u < ls + 4u) ? S - 1u - ls : 4u;
+    const long long kw = k0 + (long long)(w * PT_LW);
+
+    PlGroup A, B;
+    pl_load_group<EDGE>(A, text, n, k_soff, k_meta, kw, n_kept, ls, nval, last_q);
+#pragma unroll 1
+    for (int gp = 0; gp < PT_LW / 32; ++gp) {   // 32 lines = four groups of 8, the next group's loads in flight while one is packed
+        const long long kb = kw + (long long)(gp * 32);
+        uint32_t o0[4] = {0, 0, 0, 0}, e0[4] = {0, 0, 0, 0}, o1[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0};
+        pl_load_group<EDGE>(B, text, n, k_soff, k_meta, kb + 8, n_kept, ls, nval, last_q);
+        pl_pack_group(A, 0, o0, e0, kb, redo_list, redo_flag, cnt, lane);
+        pl_load_group<EDGE>(A, text, n, k_soff, k_meta, kb + 16, n_kept, ls, nval, last_q);
+        pl_pack_group(B, 8, o0, e0, kb + 8, redo_list, redo_flag, cnt, lane);
+        pl_load_group<EDGE>(B, text, n, k_soff, k_meta, kb + 24, n_kept, ls, nval, last_q);
+        pl_pack_group(A, 0, o1, e1, kb + 16, redo_list, redo_flag, cnt, lane);
+        if (gp + 1 < PT_LW / 32) pl_load_group<EDGE>(A, text, n, k_soff, k_meta, kb + 32, n_kept, ls, nval, last_q);
+        pl_pack_group(B, 8, o1, e1, kb + 24, redo_list, redo_flag, cnt, lane);
+        // 32 lines of this lane's four samples: one dword per (kind, plane, sample).  Image row (kind * 2 + plane) * 256
+        // + q * 64 + lane, 16 dwords; dword c of a row sits at c ^ (lane >> 2): the 64 lanes of a store hit 64 banks.
+        const uint32_t c = (w * 4u + (uint32_t)gp) ^ (lane >> 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t r = ((uint32_t)q * 64u + lane) * 16u + c;
+            img[r] = __builtin_amdgcn_perm(o1[q], o0[q], 0x05040100u);             // ONE, haplotype 0
+            img[256u * 16u + r] = __builtin_amdgcn_perm(o1[q], o0[q], 0x07060302u);   // ONE, haplotype 1
+            img[512u * 16u + r] = __builtin_amdgcn_perm(e1[q], e0[q], 0x05040100u);   // EXC, haplotype 0
+            img[768u * 16u + r] = __builtin_amdgcn_perm(e1[q], e0[q], 0x07060302u);   // EXC, haplotype 1
+        }
+    }
+    __syncthreads();
+    // image -> HBM: 1024 rows x 64 B, four lanes per row
+    uint64_t vcol = gv0 / lay.Vc;
+    const uint64_t vin = gv0 - vcol * lay.Vc;
+    if (lay.ring) vcol %= lay.ring;
+    const uint64_t bpr = lay.Vc >> 12;                       // Blosc blocks per sample row of a chunk
+    const uint32_t piece = (uint32_t)((vin & 4095ull) >> 9);  // which 64 bytes of the block's planes
+    const uint32_t nkeep = k0 < 0 ? (uint32_t)(-k0) : 0u;     // leading columns that belong to the previous call
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const uint32_t pi = (uint32_t)it * 256u + threadIdx.x;
+        const uint32_t R = pi >> 2, sl = pi & 3u;
+        const uint32_t kp = R >> 8, q = (R >> 6) & 3u, l = R & 63u;
+        const uint32_t s = s0 + 4u * l + q;
+        if (s >= S) continue;
+        const uint32_t sw = l >> 2;
+        const uint4 t = reinterpret_cast<const uint4 *>(img)[R * 4u + (sl ^ (sw >> 2))];
+        uint32_t d0 = t.x, d1 = t.y, d2 = t.z, d3 = t.w;
+        if (sw & 1u) {
+            uint32_t u = d0; d0 = d1; d1 = u;
+            u = d2; d2 = d3; d3 = u;
+        }
+        if (sw & 2u) {
+            uint32_t u = d0; d0 = d2; d2 = u;
+            u = d1; d1 = d3; d3 = u;
+        }
+        const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
+        const uint32_t sin = s - scol * lay.Sc;
+        const uint64_t blk = ((vcol * lay.n_sc + scol) * lay.Sc + sin) * bpr + (vin >> 12);
+        uint8_t *dst = P + blk * 2048ull + kp * 512u + piece * 64u + sl * 16u;
+        if (nkeep) {   // (workgroup-uniform) the tile straddles the append position
+            const uint32_t b0 = sl * 128u;
+            if (b0 + 128u <= nkeep) continue;
+            if (b0 < nkeep) {
+                const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+                const uint32_t nb = nkeep - b0;   // 1..127 low bits stay
+                const uint32_t o[4] = {old.x, old.y, old.z, old.w};
+                uint32_t d[4] = {d0, d1, d2, d3};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t km = nb >= 32u * (i + 1) ? 0xFFFFFFFFu : (nb <= 32u * i ? 0u : ((1u << (nb - 32u * i)) - 1u));
+                    d[i] = (o[i] & km) | (d[i] & ~km);
+                }
+                d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+            }
+        }
+        __builtin_nontemporal_store(u32x4_al{d0, d1, d2, d3}, reinterpret_cast<u32x4_al *>(dst));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_encode_planes(const uint8_t *__restrict__ text, uint64_t n,
+                                                          const uint32_t *__restrict__ k_soff, const uint32_t *__restrict__ k_meta,
+                                                          const uint64_t *__restrict__ d_cursor, LayoutDev lay,
+                                                          uint8_t *__restrict__ P, int8_t *__restrict__ G,
+                                                          uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
+                                                          DevCounters *cnt)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t img[1024 * 16];   // 64 KiB
+    const uint64_t v_base = *d_cursor;
+    const uint32_t n_kept = (uint32_t)cnt->n_kept;
+    // the tile row that holds the last sample (and lanes past it) reads with care; every other tile reads 16 bytes flat
+    if (blockIdx.y + 1u == gridDim.y)
+        encode_planes_tile<true>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img);
+    else
+        encode_planes_tile<false>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img);
+}
+
+// -------------------------------------------------------------------------------------------------
 // htslib vcf_parse_format GT rule (see oracle/vcf_oracle.c parse_gt for the restatement it mirrors)
 template <typename RD>
 __device__ __forceinline__ uint32_t parse_gt_bytes(RD rd, uint32_t p, uint32_t lim, uint32_t *n_alleles)
@@ -227,13 +476,17 @@ __device__ __forceinline__ uint32_t parse_gt_bytes(RD rd, uint32_t p, uint32_t l
 
 #define GEN_HALO 64u  // bytes staged past each 1 KiB piece: a GT sub-field that starts in the piece ends inside it
 
+// PLANES: the bit-plane form (k_encode_planes wrote zeros for every call of the lines this kernel owns; the bits are set
+// by atomic or, the bytes of calls beyond 0 / 1 / missing go to their place in G)
+template <bool PLANES>
 __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restrict__ text, uint64_t n,
                                                         const uint32_t *__restrict__ k_soff,
                                                         const uint32_t *__restrict__ k_lend,
                                                         const uint32_t *__restrict__ k_meta,
                                                         const uint32_t *__restrict__ redo_list,
                                                         const uint64_t *__restrict__ d_cursor,
-                                                        LayoutDev lay, int8_t *__restrict__ G, DevCounters *cnt)
+                                                        LayoutDev lay, int8_t *__restrict__ G, uint8_t *__restrict__ P,
+                                                        DevCounters *cnt)
 {
     const uint64_t v_base = *d_cursor;
     const uint32_t lane = threadIdx.x & 63u;
@@ -328,8 +581,31 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 if (na == 1u) ++haploid;
                 const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
                 const uint32_t sin = s - scol * lay.Sc;
-                int8_t *dst = G + ((((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull);
-                *reinterpret_cast<uint16_t *>(dst) = (uint16_t)hv;
+                const uint64_t goff = (((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull;
+                if (!PLANES) {
+                    *reinterpret_cast<uint16_t *>(G + goff) = (uint16_t)hv;
+                } else {
+                    const uint32_t bit = (uint32_t)(goff & 8191ull) >> 1;
+                    uint32_t *pw = reinterpret_cast<uint32_t *>(P + (goff >> 13) * 2048ull) + (bit >> 5);
+                    const uint32_t mk = 1u << (bit & 31u);
+                    const uint32_t h0 = hv & 0xFFu, h1 = (hv >> 8) & 0xFFu;
+                    if (h0 == 1u || h0 == 0xF7u) atomicOr(pw, mk);
+                    if (h1 == 1u || h1 == 0xF7u) atomicOr(pw + 128, mk);
+                    if (h0 > 1u) {
+                        atomicOr(pw + 256, mk);
+                        if (h0 != 0xF7u) {
+                            atomicAdd(&cnt->n_other, 1ull);
+                            if (G) G[goff] = (int8_t)h0;
+                        }
+                    }
+                    if (h1 > 1u) {
+                        atomicOr(pw + 384, mk);
+                        if (h1 != 0xF7u) {
+                            atomicAdd(&cnt->n_other, 1ull);
+                            if (G) G[goff + 1ull] = (int8_t)h1;
+                        }
+                    }
+                }
             }
             tabs_before += __shfl(inc, 63, 64);
         }
@@ -434,11 +710,136 @@ int launch_encode_tiles(const uint8_t *d_text, uint64_t n, const uint32_t *k_sof
 
 int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_lend,
                           const uint32_t *k_meta, const uint32_t *redo_list, const uint64_t *d_cursor, LayoutDev lay,
-                          int8_t *d_G, DevCounters *d_cnt, int n_cu, hipStream_t st)
+                          int8_t *d_G, uint8_t *d_P, DevCounters *d_cnt, int n_cu, hipStream_t st)
 {
     if (lay.S == 0) return HHGT_OK;
-    hipLaunchKernelGGL(k_encode_general, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
-                       k_meta, redo_list, d_cursor, lay, d_G, d_cnt);
+    if (d_P)
+        hipLaunchKernelGGL(k_encode_general<true>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
+                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt);
+    else
+        hipLaunchKernelGGL(k_encode_general<false>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
+                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_encode_planes(const uint8_t *d_text, uint64_t n, const uint32_t *k_soff, const uint32_t *k_meta,
+                         uint32_t n_lines_bound, const uint64_t *d_cursor, LayoutDev lay, uint8_t *d_P, int8_t *d_G,
+                         uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st)
+{
+    if (n_lines_bound == 0 || lay.S == 0) return HHGT_OK;
+    const uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
+    // the append position is only known on the device: one tile more than the lines need covers any phase
+    const uint64_t tiles_v = ((uint64_t)(PT_V - 1) + (uint64_t)n_lines_bound + (PT_V - 1)) / PT_V;
+    hipLaunchKernelGGL(k_encode_planes, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff, k_meta, d_cursor,
+                       lay, d_P, d_G, redo_list, redo_flag, d_cnt);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// planes: zero the bits of variants [c0, Vc) of padded sample rows [r0, r1) of chunk columns vcol0 + blockIdx.z
+// (rows >= S: the whole row).  grid.x = Blosc blocks per sample row, 128 threads = the 128 dwords of a plane.
+__device__ __forceinline__ void zero_planes_row(const LayoutDev &lay, uint64_t vcol, uint32_t r, uint64_t c0, uint8_t *__restrict__ P)
+{
+    const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (r >> lay.sc_log2);
+    const uint32_t sin = r - scol * lay.Sc;
+    const uint64_t bpr = lay.Vc >> 12;
+    for (uint64_t b = blockIdx.x; b < bpr; b += gridDim.x) {
+        const uint64_t lo = b * 4096ull + 32ull * threadIdx.x;   // first variant of this thread's dword
+        if (lo + 32ull <= c0) continue;
+        const uint32_t keep = lo >= c0 ? 0u : ((1u << (uint32_t)(c0 - lo)) - 1u);
+        uint32_t *p = reinterpret_cast<uint32_t *>(P + (((vcol * lay.n_sc + scol) * lay.Sc + sin) * bpr + b) * 2048ull) + threadIdx.x;
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) p[128 * kp] = keep ? (p[128 * kp] & keep) : 0u;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_zero_planes_rect(LayoutDev lay, uint64_t vcol0, uint32_t r0, uint32_t r1, uint64_t c0,
+                                                          uint8_t *__restrict__ P)
+{
+    const uint32_t r = r0 + blockIdx.y;
+    if (r >= r1) return;
+    zero_planes_row(lay, vcol0 + blockIdx.z, r, c0, P);
+}
+
+__global__ __launch_bounds__(128) void k_zero_planes_cursor(LayoutDev lay, const uint64_t *__restrict__ d_cursor, uint8_t *__restrict__ P)
+{
+    const uint64_t v_end = *d_cursor;
+    uint64_t vcol = v_end / lay.Vc;
+    const uint64_t c0 = v_end - vcol * lay.Vc;
+    if (c0 == 0) return;                       // the cursor sits on a column boundary: nothing is open
+    if (lay.ring) vcol %= lay.ring;
+    const uint32_t r = blockIdx.y;             // padded sample row
+    zero_planes_row(lay, vcol, r, r < lay.S ? c0 : 0ull, P);
+}
+
+int launch_pad_tail_planes_cursor(LayoutDev lay, const uint64_t *d_cursor, uint8_t *d_P, hipStream_t st)
+{
+    const uint32_t S_pad = lay.n_sc * lay.Sc;
+    if (S_pad == 0) return HHGT_OK;
+    const uint64_t bpr = lay.Vc >> 12;
+    hipLaunchKernelGGL(k_zero_planes_cursor, dim3((uint32_t)(bpr < 64 ? bpr : 64), S_pad), dim3(128), 0, st, lay, d_cursor, d_P);
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+int launch_pad_tail_planes(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, uint8_t *d_P, hipStream_t st)
+{
+    const uint32_t S_pad = lay.n_sc * lay.Sc;
+    const uint64_t bpr = lay.Vc >> 12;
+    const uint32_t gx = (uint32_t)(bpr < 64 ? bpr : 64);
+    if (v_end % lay.Vc) {   // (a) variant padding of the last touched chunk column
+        const uint64_t vcol = v_end / lay.Vc;
+        if (vcol < vcol_end && vcol >= vcol_begin && S_pad)
+            hipLaunchKernelGGL(k_zero_planes_rect, dim3(gx, S_pad), dim3(128), 0, st, lay, vcol, 0u, S_pad, v_end - vcol * lay.Vc, d_P);
+    }
+    if (S_pad > lay.S) {    // (b) sample padding rows of every touched chunk column
+        for (uint64_t v0 = vcol_begin; v0 < vcol_end; v0 += 65535) {
+            const uint32_t nz = (uint32_t)(vcol_end - v0 < 65535 ? vcol_end - v0 : 65535);
+            hipLaunchKernelGGL(k_zero_planes_rect, dim3(gx, S_pad - lay.S, nz), dim3(128), 0, st, lay, v0, lay.S, S_pad, 0ull, d_P);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return HHGT_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// planes -> int8 bytes of the block (the inverse of the packing; for consumers that want the matrix after all and for
+// the parity tests).  One workgroup per Blosc block, thread t owns variants [16 t, 16 t + 16).
+__global__ __launch_bounds__(256) void k_planes_expand(const uint8_t *__restrict__ P, const uint8_t *G, uint8_t *out)   // out may be G
+{
+    const uint64_t blk = blockIdx.x;
+    const uint16_t *pl = reinterpret_cast<const uint16_t *>(P + blk * 2048ull);
+    const uint32_t t = threadIdx.x;
+    const uint32_t o0 = pl[t], o1 = pl[256 + t], e0 = pl[512 + t], e1 = pl[768 + t];
+    const uint64_t base = blk * 8192ull + 32ull * t;
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 2 * i + k;
+            uint32_t h0 = (o0 >> j) & 1u, h1 = (o1 >> j) & 1u;
+            if ((e0 >> j) & 1u) h0 = h0 ? 0xF7u : (G ? (uint32_t)G[base + 2u * j] : 0u);
+            if ((e1 >> j) & 1u) h1 = h1 ? 0xF7u : (G ? (uint32_t)G[base + 2u * j + 1u] : 0u);
+            x |= (h0 | (h1 << 8)) << (16 * k);
+        }
+        w[i] = x;
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + base);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+int launch_planes_expand(const uint8_t *d_P, const uint8_t *d_G, uint64_t n_blocks, uint8_t *d_out, hipStream_t st)
+{
+    for (uint64_t b0 = 0; b0 < n_blocks; b0 += 0x40000000ull) {
+        const uint64_t nb = n_blocks - b0 < 0x40000000ull ? n_blocks - b0 : 0x40000000ull;
+        hipLaunchKernelGGL(k_planes_expand, dim3((uint32_t)nb), dim3(256), 0, st, d_P + b0 * 2048ull, d_G ? d_G + b0 * 8192ull : nullptr,
+                           d_out + b0 * 8192ull);
+    }
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
                                                      uint32_t *__restrict__ csize, const uint32_t *__restrict__ marked,
-                                                     const uint32_t *__restrict__ n_marked)
+                                                     const uint32_t *__restrict__ n_marked, const uint8_t *__restrict__ planes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
@@ -679,7 +679,25 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     const uint8_t *blk = src + chunk * chunk_nbytes + boff;
 
     // ---- phase A: load + byte-shuffle into LDS
-    if (typesize == 1u) {
+    if (planes) {
+        // the block exists as bit planes (include/hhgt.h "Bit-plane form"; typesize 2, 8 KiB blocks): the shuffled byte
+        // planes are generated from the bits; bytes of calls beyond 0 / 1 / missing come from their place in src
+        const uint8_t *pl = planes + (uint64_t)bid * 2048u;
+        for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) {   // byte i of each plane = variants 8 i .. 8 i + 7
+            const uint32_t o[2] = {pl[i], pl[512u + i]}, e[2] = {pl[1024u + i], pl[1536u + i]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t w[2] = {0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t v = (o[h] >> k) & 1u;
+                    if ((e[h] >> k) & 1u) v = v ? 0xF7u : (src ? (uint32_t)blk[(8u * i + (uint32_t)k) * 2u + (uint32_t)h] : 0u);
+                    w[k >> 2] |= v << (8 * (k & 3));
+                }
+                *reinterpret_cast<uint2 *>(data + (uint32_t)h * pstride + 8u * i) = make_uint2(w[0], w[1]);
+            }
+        }
+    } else if (typesize == 1u) {
         for (uint32_t i = threadIdx.x * 16u; i < bsize; i += blockDim.x * 16u) {
             if (i + 16u <= bsize && ((reinterpret_cast<uintptr_t>(blk + i) & 15u) == 0))
                 *reinterpret_cast<uint4 *>(data + i) = *reinterpret_cast<const uint4 *>(blk + i);
@@ -735,23 +753,27 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     }
 }
 
-int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
                       int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
                       uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st)
 {
+    if (d_planes && (typesize != 2 || blocksize != 8192 || chunk_nbytes % 8192 || (reinterpret_cast<uintptr_t>(d_planes) & 15u))) {
+        hhgt_set_error("lz4: bit planes stand for typesize 2, 8 KiB blocks, chunks of whole blocks, 16-byte aligned");
+        return HHGT_ERR_ARG;
+    }
     const int fast = clevel <= 2 ? 1 : (clevel >= 7 ? 2 : 0);
     // the bit-plane encoder (lz4bits.hip) takes the case the path is built for — typesize 2, 8 KiB blocks, default
     // effort — and marks the streams it cannot code (a byte > 1, very dense planes); this kernel then only runs those.
     // HHGT_LZ4_BITPLANES=0 keeps everything on the byte-wise encoder.
     static const bool bp_env = !(getenv("HHGT_LZ4_BITPLANES") && atoi(getenv("HHGT_LZ4_BITPLANES")) == 0);
     const bool bitplanes = bp_env && typesize == 2 && blocksize == 8192 && chunk_nbytes % 8192 == 0 &&
-                           (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0 && slot_bytes >= 4128 && d_marked && d_n_marked;
+                           (d_planes || (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0) && slot_bytes >= 4128 && d_marked && d_n_marked;
     if (bitplanes) {
         // effort: candidates tried per one along the hash chain (clevel 1-2: none, offset-1 runs only)
         static const int depth_env = getenv("HHGT_LZ4_DEPTH") ? atoi(getenv("HHGT_LZ4_DEPTH")) : -1;
         const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 16);
-        const int rc = launch_lz4_bitplanes(d_src, n_chunks * (chunk_nbytes / 8192), d_scratch, slot_bytes, d_csize, d_marked,
-                                            d_n_marked, depth, st);
+        const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, n_chunks * (chunk_nbytes / 8192), d_scratch,
+                                            slot_bytes, d_csize, d_marked, d_n_marked, depth, st);
         if (rc != HHGT_OK) return rc;
     }
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
@@ -823,7 +845,7 @@ int launch_lz4_blocks(const uint8_t *d_src, uint64_t n_chunks, uint64_t chunk_nb
 #define LZ_LAUNCH(MWV, ALG)                                                                                          \
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
-                       (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked)
+                       (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked, d_planes)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)
     if ((algo & 0xFFu) == 1u) LZ_LAUNCH(0, 1);

@@ -185,7 +185,9 @@ __device__ __forceinline__ void bp_flush(const uint8_t *stage, uint8_t *__restri
 // grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
 // DEPTH = candidates tried per one along the hash chain (1: the table's entry only; 0: no hash matches at all,
 // offset-1 runs only — the fastest level)
-template <int DEPTH>
+// PLANES: src is the bit-plane form of the matrix (include/hhgt.h; 2048 bytes per block, written by k_encode_planes):
+// the wave's bit map is 512 bytes it loads as they are, and a set EXC bit is what "a byte > 1" was.
+template <int DEPTH, bool PLANES>
 __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, uint8_t *__restrict__ scratch,
                                                           uint64_t slot_bytes, uint32_t *__restrict__ csize,
                                                           uint32_t *__restrict__ marked, uint32_t *__restrict__ n_marked)
@@ -195,6 +197,21 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     __shared__ uint32_t nonbin[2][2];
     __shared__ uint32_t queued;   // the block goes into the byte-wise encoder's list once, whichever wave asks first
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    uint32_t wlo, whi;
+    bool nonbinary;
+    if (PLANES) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 *pl = reinterpret_cast<const u32x2 *>(src + (uint64_t)blockIdx.x * 2048u + 512u * wave) + lane;
+        const u32x2 one = __builtin_nontemporal_load(pl), exc = __builtin_nontemporal_load(pl + 128);   // streamed once
+        wlo = one.x;
+        whi = one.y;
+        lds[wave].bm[2u * lane] = wlo;
+        lds[wave].bm[2u * lane + 1u] = whi;
+        nonbinary = __builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) != 0ull;
+        if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
+        if (threadIdx.x == 0) queued = 0u;
+        __syncthreads();   // (for `queued` only: each wave works on what it loaded itself)
+    } else {
     const uint8_t *blk = src + (uint64_t)blockIdx.x * 8192u;
 
     // ---- phase A: wave r packs the bits of block bytes [4096 r, 4096 r + 4096) for BOTH planes (byte-shuffle fused:
@@ -237,8 +254,12 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
         if (threadIdx.x == 0) queued = 0u;
     }
-    BP_MARK("A_done");
     __syncthreads();
+    wlo = lds[wave].bm[2u * lane];
+    whi = lds[wave].bm[2u * lane + 1u];
+    nonbinary = (nonbin[0][wave] | nonbin[1][wave]) != 0u;
+    }
+    BP_MARK("A_done");
 #ifndef BP_SKIP
 #define BP_SKIP 0   // development: 1 no emission, 2 no layout either, 3 no selection, 4 no window loop, 5 phase A only (invalid output; timing only)
 #endif
@@ -263,11 +284,10 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     const uint64_t sidx = (uint64_t)blockIdx.x * 2u + wave;
     uint8_t *out = scratch + sidx * slot_bytes;
 
-    const uint32_t wlo = bm[2u * lane], whi = bm[2u * lane + 1u];
     const uint32_t cnt = (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
     const uint32_t incl = bp_scan_sum(cnt, lane);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if ((nonbin[0][wave] | nonbin[1][wave]) != 0u || m > BP_MAXONES) {
+    if (nonbinary || m > BP_MAXONES) {
         if (lane == 0) {   // left to the byte-wise encoder: mark the stream, queue its block (once: two workgroups on one
             csize[sidx] = 0xFFFFFFFFu;   // block would write two different valid encodings into the same slot)
             if (atomicExch(&queued, 1u) == 0u) marked[atomicAdd(n_marked, 1u)] = blockIdx.x;
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     if (lane == 0) csize[sidx] = op;
 }
 
-int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
                          uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st)
 {
     if (n_blocks == 0) return HHGT_OK;
@@ -586,9 +606,14 @@ int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scr
     // development: extra (unused) dynamic LDS per workgroup caps how many workgroups a CU holds, which leaves LDS and
     // wave slots to a kernel running beside this one on another stream
     static const int lds_pad = getenv("HHGT_LZ4_LDS_PAD") ? atoi(getenv("HHGT_LZ4_LDS_PAD")) : 0;
-#define BP_LAUNCH(D)                                                                                                       \
-    hipLaunchKernelGGL((k_lz4_bitplanes<D>), dim3((uint32_t)n_blocks), dim3(128), lds_pad, st, d_src, d_scratch, (uint64_t)slot_bytes, \
+#define BP_LAUNCH2(D, PL)                                                                                                   \
+    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL>), dim3((uint32_t)n_blocks), dim3(128), lds_pad, st, d_src, d_scratch, (uint64_t)slot_bytes, \
                        d_csize, d_marked, d_n_marked)
+#define BP_LAUNCH(D)            \
+    do {                        \
+        if (planes) BP_LAUNCH2(D, true); \
+        else BP_LAUNCH2(D, false);       \
+    } while (0)
     if (depth <= 0) BP_LAUNCH(0);
     else if (depth == 1) BP_LAUNCH(1);
     else if (depth == 2) BP_LAUNCH(2);
@@ -596,6 +621,7 @@ int launch_lz4_bitplanes(const uint8_t *d_src, uint64_t n_blocks, uint8_t *d_scr
     else if (depth <= 8) BP_LAUNCH(8);
     else BP_LAUNCH(16);
 #undef BP_LAUNCH
+#undef BP_LAUNCH2
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

@@ -53,6 +53,12 @@ def layout_bytes(lay):
     return int(_lib.load().hhgt_layout_bytes(C.byref(lay)))
 
 
+def planes_bytes(lay):
+    """bytes of the bit-plane form of the matrix under `lay` (a quarter of layout_bytes; 0: the layout cannot carry
+    planes — variants per chunk must be a multiple of 4096)"""
+    return int(_lib.load().hhgt_planes_bytes(C.byref(lay)))
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -72,6 +78,7 @@ class EncodeResult:
     n_kept: int
     stats: dict
     chrom_runs: list = field(default_factory=list)   # [(first_kept_index, name)]
+    P: torch.Tensor = None     # bit-plane form of the matrix (include/hhgt.h), when the encode produced that instead of G
 
     def dense(self):
         """int8 [S, n_kept, 2] torch tensor (device) gathered out of the chunk-tiled buffer."""
@@ -190,6 +197,65 @@ class Context:
     def pad_tail_cursor(self, res, cursor):
         with torch.cuda.device(self.device):
             check(self.lib.hhgt_pad_tail_cursor(self.h, C.byref(res.layout), _ptr(cursor), _ptr(res.G), _stream()))
+
+    # ---- bit-plane form of the matrix (include/hhgt.h "Bit-plane form": compressor-only consumers) -------------------
+    def encode_text_planes_async(self, text, n_samples, out, cursor, max_lines=None, region="", pending=None):
+        """hhgt_encode_text_planes_async: like encode_text_async, but the calls land in out.P as two bits per allele;
+        out.G (may be None) only receives the bytes of calls beyond 0 / 1 / missing.  -> PendingEncode
+        (.rec.reserved = number of such calls)"""
+        assert text.is_cuda and text.dtype == torch.uint8 and text.is_contiguous() and out.P is not None
+        nbytes = text.numel()
+        if max_lines is None:
+            max_lines = nbytes // (16 + 2 * max(n_samples, 0)) + 64
+        pending = pending or PendingEncode()
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_encode_text_planes_async(self.h, _ptr(text), nbytes, (region or "").encode(),
+                                                         C.byref(out.layout), _ptr(cursor), int(max_lines), _ptr(out.P), _ptr(out.G),
+                                                         _ptr(out.start), _ptr(out.stop), _ptr(out.ref), _ptr(out.alt),
+                                                         C.c_void_p(pending.buf.data_ptr()), _stream()))
+            pending.event.record(torch.cuda.current_stream())
+        return pending
+
+    def pad_tail_planes_cursor(self, res, cursor):
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_pad_tail_planes_cursor(self.h, C.byref(res.layout), _ptr(cursor), _ptr(res.P), _stream()))
+
+    def pad_tail_planes(self, res, v_end, vcol_begin=0, vcol_end=None):
+        lay = res.layout
+        Vc = lay.vc or lay.v_capacity
+        if vcol_end is None:
+            vcol_end = -(-max(v_end, 1) // Vc)
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_pad_tail_planes(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end), _ptr(res.P), _stream()))
+
+    def compress_planes(self, P, G, chunk_nbytes, fmt=BLOSC2, dst=None, chunk_off=None, sync=True):
+        """hhgt_compress_planes: P holds the planes of n_chunks chunks of chunk_nbytes int8 bytes each (typesize 2,
+        8 KiB blocks); G (or None) the int8 matrix whose bytes back the calls beyond 0 / 1 / missing.
+        -> (dst, chunk_off, total_bytes or None) like compress()"""
+        assert P.is_cuda and P.dtype == torch.uint8 and P.is_contiguous()
+        chunk_nbytes = int(chunk_nbytes)
+        assert chunk_nbytes % 8192 == 0 and (P.numel() * 4) % chunk_nbytes == 0
+        n_chunks = P.numel() * 4 // chunk_nbytes
+        with torch.cuda.device(self.device):
+            cap = int(self.lib.hhgt_compress_bound(n_chunks, chunk_nbytes, 2, 8192))
+            if dst is None:
+                dst = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            if chunk_off is None:
+                chunk_off = torch.zeros(n_chunks + 1, dtype=torch.int64, device=self.device)
+            total = C.c_uint64(0)
+            check(self.lib.hhgt_compress_planes(self.h, _ptr(P), _ptr(G), n_chunks, chunk_nbytes, fmt, _ptr(dst), dst.numel(),
+                                                _ptr(chunk_off), C.byref(total) if sync else None, _stream()))
+        return dst, chunk_off, (int(total.value) if sync else None)
+
+    def planes_expand(self, P, G=None, out=None):
+        """hhgt_planes_expand: planes (+ G's bytes for the calls beyond 0 / 1 / missing) -> the int8 matrix bytes"""
+        assert P.is_cuda and P.dtype == torch.uint8 and P.numel() % 2048 == 0
+        n_blocks = P.numel() // 2048
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty(n_blocks * 8192, dtype=torch.uint8, device=self.device)
+            check(self.lib.hhgt_planes_expand(self.h, _ptr(P), _ptr(G), n_blocks, _ptr(out), _stream()))
+        return out
 
     def chrom_runs(self):
         n = C.c_uint32(0)

@@ -205,6 +205,43 @@ int hhgt_decompress_chunks(hhgt_ctx *ctx, const void *d_src, const uint64_t *d_c
                            void *d_dst, uint64_t *n_bad, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Bit-plane form of the genotype matrix: the intermediate between encode and compress when the compressor is the only
+ * consumer of the matrix (converter, ingest engine, bench).  Same path, same results — the int8 values
+ * cpp/parse_vcf.cpp:46-61 produces and the chunks src/haplohyped/vcf_to_h5.py:131-135 stores — but the 2*S bytes per
+ * variant between the two halves shrink to S/2: the encoder writes, and the LZ4 coder reads, two BITS per allele.
+ *
+ * Geometry: typesize 2, Blosc blocks of 8192 bytes (= one sample x 4096 variants x 2 haplotypes), so the layout needs
+ * vc % 4096 == 0 (dense: v_capacity % 4096 == 0).  Block b of G (bytes [8192 b, 8192 b + 8192) of the chunk-tiled
+ * matrix, any layout incl. rings) has its planes at d_P + 2048 b:
+ *     [   0,  512)  ONE bits, haplotype 0      bit i (little-endian dwords, LSB first) = variant i of the block
+ *     [ 512, 1024)  ONE bits, haplotype 1
+ *     [1024, 1536)  EXC bits, haplotype 0
+ *     [1536, 2048)  EXC bits, haplotype 1
+ * (ONE, EXC) = (0,0): allele 0; (1,0): allele 1; (1,1): missing, -9 (cpp/vcfpp.h:567-573); (0,1): any other value
+ * (allele index >= 2, cpp/vcfpp.h:574) — its int8 byte sits at the call's ordinary position in d_G, which is written
+ * there and nowhere else.  hhgt_encode_result.reserved counts those calls (saturating); d_G may be NULL where the
+ * caller knows there are none (biallelic input under the reference's filter has none).
+ *
+ * hhgt_encode_text_planes_async / hhgt_pad_tail_planes_cursor / hhgt_pad_tail_planes: as their int8 namesakes.
+ * hhgt_compress_planes: as hhgt_compress_chunks with typesize 2, blocksize 8192 on the matrix the planes stand for
+ *   (chunk_nbytes = int8 bytes of a chunk, a multiple of 8192; d_P holds n_chunks * chunk_nbytes / 4 bytes).
+ * hhgt_planes_expand: planes (+ d_G's bytes for the (0,1) calls) -> int8 bytes, n_blocks blocks of 8192 bytes into
+ *   d_out (d_out == d_G is allowed).  For consumers that want the matrix after all, and for the parity tests.
+ * ------------------------------------------------------------------------------------------- */
+uint64_t hhgt_planes_bytes(const hhgt_layout *lay);   /* 0 if the layout cannot carry planes */
+int hhgt_encode_text_planes_async(hhgt_ctx *ctx, const void *d_text, uint64_t nbytes, const char *region,
+                                  const hhgt_layout *lay, uint64_t *d_cursor, uint32_t max_lines, void *d_P, void *d_G,
+                                  uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt,
+                                  hhgt_encode_result *h_result, void *stream);
+int hhgt_pad_tail_planes_cursor(hhgt_ctx *ctx, const hhgt_layout *lay, const uint64_t *d_cursor, void *d_P, void *stream);
+int hhgt_pad_tail_planes(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end,
+                         void *d_P, void *stream);
+int hhgt_compress_planes(hhgt_ctx *ctx, const void *d_P, const void *d_G, uint64_t n_chunks, uint64_t chunk_nbytes,
+                         int format, void *d_dst, uint64_t dst_cap, uint64_t *d_chunk_off, uint64_t *total_bytes,
+                         void *stream);
+int hhgt_planes_expand(hhgt_ctx *ctx, const void *d_P, const void *d_G, uint64_t n_blocks, void *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Consumer side (BASELINE config 5): one-hot haplotype windows straight into a device tensor.
  * Replaces the per-item numpy work of RandomHaplotypeDataset.__getitem__ / encode_haplotypes /
  * encode_sequence (/root/reference/src/datasets/haplotype_dataset.py:54-110,
@@ -275,27 +312,28 @@ int hhgt_inflate_members(hhgt_ctx *ctx, const void *d_src, uint64_t src_bytes, c
 #define HHGT_STAGE_FRAME 5    /* Blosc2 framing / compaction                                     */
 #define HHGT_STAGE_DECODE 6   /* chunk decode                                                    */
 #define HHGT_STAGE_ONEHOT 7   /* one-hot haplotype windows                                       */
-#define HHGT_STAGE_INFLATE 8  /* Streams for callers that run hhgt_compress_chunks of one block BESIDE hhgt_encode_text_async of the next (two
- * streams, events in between; what bench.py does).  Both are plain hipStream_t values, usable wherever this header takes
- * `void *stream`.
+#define HHGT_STAGE_INFLATE 8  /* BGZF members inflated on the device                            */
+#define HHGT_N_STAGES 9
+int hhgt_profile_enable(hhgt_ctx *ctx, int on);
+int hhgt_profile_reset(hhgt_ctx *ctx);
+int hhgt_profile_read(hhgt_ctx *ctx, double *ms /*[HHGT_N_STAGES]*/, uint64_t *launches /*[HHGT_N_STAGES]*/);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streams for callers that run the compress step of one block BESIDE hhgt_encode_text*_async of the next (two
+ * streams, events in between; what bench.py does).  Both are plain hipStream_t values, usable wherever this header
+ * takes `void *stream`.
  *   HHGT_STREAM_ENCODE    high priority, every CU
  *   HHGT_STREAM_COMPRESS  default priority, restricted (hipExtStreamCreateWithCUMask) to 3/4 of the CUs: the LZ4 kernel
  *                         is bound by instruction issue and fills every CU it may use with resident waves, and the
  *                         encode chain of the next block — two HBM-bound passes with latency-bound small kernels in
  *                         between — then waits for slots one workgroup at a time (k_parse_fixed: 146 us beside LZ4, 40 us
- *                         alone).  With a quarter of the chip kept free of LZ4 the step of the 3 M x 2504 cohort takes
- *                         24.7-25.3 instead of 26.3 ms.  HHGT_COMPRESS_CUS=n overrides the CU count (0 = all).
- * Destroy with hhgt_stream_destroy before hhgt_ctx_destroy. */
+ *                         alone).  HHGT_COMPRESS_CUS=n overrides the CU count (0 = all).
+ * Destroy with hhgt_stream_destroy before hhgt_ctx_destroy.
+ * ------------------------------------------------------------------------------------------- */
 #define HHGT_STREAM_ENCODE 0
 #define HHGT_STREAM_COMPRESS 1
 int hhgt_stream_create(hhgt_ctx *ctx, int kind, void **stream);
 int hhgt_stream_destroy(hhgt_ctx *ctx, void *stream);
-
-/* BGZF members inflated on the device                            */
-#define HHGT_N_STAGES 9
-int hhgt_profile_enable(hhgt_ctx *ctx, int on);
-int hhgt_profile_reset(hhgt_ctx *ctx);
-int hhgt_profile_read(hhgt_ctx *ctx, double *ms /*[HHGT_N_STAGES]*/, uint64_t *launches /*[HHGT_N_STAGES]*/);
 
 #ifdef __cplusplus
 }
