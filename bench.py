@@ -4,9 +4,10 @@
 One "step" = one pass of the hot path over the whole workload: for each of the 22 per-chromosome
 shards (3 000 000 variants x 2504 samples, BASELINE.json configs[2] — the configuration the metric
 is quoted on; ~30 GB of text, fits one MI355X):
-    hhgt_encode_text_async (line index -> fixed columns/filter -> GT tiles)  ->  int8 G, chunk-tiled
-    hhgt_pad_tail_cursor
-    hhgt_compress_chunks (byte-shuffle + LZ4 -> Blosc2-framed chunks)
+    hhgt_encode_text_planes_async (line index -> fixed columns/filter -> GT tiles)  ->  the genotype matrix as two
+                                   bits per allele (include/hhgt.h "Bit-plane form"; --intermediate int8: the int8 matrix)
+    hhgt_pad_tail_planes_cursor
+    hhgt_compress_planes (byte-shuffle + LZ4 -> Blosc2-framed chunks that decode to the int8 matrix)
 Inputs (raw VCF text) are generated ON the GPU (csrc/synth.hip) before the timed region; nothing in the
 step waits on the host.  `value` is this kernel-only leg.  Outside the timed region and
 outside `value`, rank 0 at N = 1 also reports
@@ -49,6 +50,8 @@ def parse_args():
     ap.add_argument("--vc", type=int, default=8192, help="variants per chunk (chunk = 64 x vc x 2 bytes)")
     ap.add_argument("--blocksize", type=int, default=8192, help="Blosc2 block bytes")
     ap.add_argument("--clevel", type=int, default=5, help="codec level (reference: 5); 1-2 = run-only fast mode")
+    ap.add_argument("--intermediate", choices=["planes", "int8"], default="planes",
+                    help="what the encoder hands the compressor: bit planes (2 bits per allele) or the int8 matrix (round 2's step)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no encode/compress overlap")
     ap.add_argument("--lookahead", type=int, default=1, help="shards the encode stream runs ahead of the compress stream")
     ap.add_argument("--dist-backend", default="", help="nccl (= RCCL; default) or gloo (ranks sharing one GPU in rehearsals)")
@@ -111,13 +114,18 @@ def build_shards(ctx, args, rank, world):
         sh.layout = dev.make_layout(S, V, vc=args.vc)
         cap = sh.layout.v_capacity
         d = ctx.device
-        sh.res = dev.EncodeResult(torch.zeros(dev.layout_bytes(sh.layout), dtype=torch.uint8, device=d), sh.layout,
+        planes = args.intermediate == "planes"
+        # planes: the int8 matrix does not exist during the step (synthetic biallelic text has no calls beyond 0 / 1 /
+        # missing, so nothing needs a byte in G); the gate expands the planes afterwards
+        G = None if planes else torch.zeros(dev.layout_bytes(sh.layout), dtype=torch.uint8, device=d)
+        P = torch.zeros(dev.planes_bytes(sh.layout), dtype=torch.uint8, device=d) if planes else None
+        sh.res = dev.EncodeResult(G, sh.layout,
                                   torch.zeros(cap, dtype=torch.int32, device=d),
                                   torch.zeros(cap, dtype=torch.int32, device=d),
                                   torch.zeros(cap, dtype=torch.uint8, device=d),
-                                  torch.zeros(cap, dtype=torch.uint8, device=d), 0, {})
+                                  torch.zeros(cap, dtype=torch.uint8, device=d), 0, {}, [], P)
         sh.chunk_nbytes = sh.layout.sc * sh.layout.vc * 2
-        sh.n_chunks = sh.res.G.numel() // sh.chunk_nbytes
+        sh.n_chunks = dev.layout_bytes(sh.layout) // sh.chunk_nbytes
         sh.dst = torch.empty(sh.n_chunks * (sh.chunk_nbytes + 32), dtype=torch.uint8, device=d)
         sh.off = torch.zeros(sh.n_chunks + 1, dtype=torch.int64, device=d)
         sh.cmp_done = None
@@ -155,12 +163,19 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
 
     def encode(sh):
         sh.cursor.zero_()
-        ctx.encode_text_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
-        ctx.pad_tail_cursor(sh.res, sh.cursor)
+        if sh.res.P is not None:
+            ctx.encode_text_planes_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
+            ctx.pad_tail_planes_cursor(sh.res, sh.cursor)
+        else:
+            ctx.encode_text_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
+            ctx.pad_tail_cursor(sh.res, sh.cursor)
 
     def compress(sh):
-        ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2, dst=sh.dst,
-                     chunk_off=sh.off, sync=False)
+        if sh.res.P is not None:
+            ctx.compress_planes(sh.res, fmt=dev.BLOSC2, dst=sh.dst, chunk_off=sh.off, sync=False)
+        else:
+            ctx.compress(sh.res.G, sh.chunk_nbytes, typesize=2, blocksize=blocksize, fmt=dev.BLOSC2, dst=sh.dst,
+                         chunk_off=sh.off, sync=False)
 
     if streams is None:
         for sh in shards:
@@ -195,41 +210,62 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
 # correctness gate (outside the timed region)
 # ---------------------------------------------------------------------------------------------------------------
 def correctness_gate(ctx, shards, S, blocksize):
-    """What the timed steps left in HBM is checked three ways; any mismatch raises (the run exits non-zero).
-    (1) every shard: its framed chunks are decoded by the GPU decoder and compared with G byte for byte;
-    (2) every shard: 64 sampled variants of G against the generator's rule (synth.genotype_bits) — the encode side;
-    (3) two chunks (first shard's first, last shard's last) are decoded by the CPU oracle."""
+    """What the timed steps left in HBM is checked; any mismatch raises (the run exits non-zero).  Per shard:
+    (0) planes step: the planes are expanded to the int8 matrix G they stand for, and the same text is encoded once more
+        by the int8 kernel (k_encode_tiles) — the two must agree byte for byte;
+    (1) the framed chunks are decoded by the GPU decoder and compared with G byte for byte;
+    (2) 64 sampled variants of G against the generator's rule (synth.genotype_bits) — the encode side;
+    (3) one chunk (a different position in every shard) is decoded by the CPU oracle and compared with G."""
     import numpy as np
     import torch
-    from haplohyped_varawareml_amd import synth
+    from haplohyped_varawareml_amd import device as dev, synth
     from oracle import oracle
-    rep = dict(shards=len(shards), chunks_decoded_gpu=0, variants_sampled=0, chunks_decoded_oracle=0)
+    rep = dict(shards=len(shards), chunks_decoded_gpu=0, variants_sampled=0, chunks_decoded_oracle=0, shards_cross_checked_int8=0)
     rng = np.random.default_rng(12345)
-    for sh in shards:
+    for si, sh in enumerate(shards):
         rec = sh.pending.wait()                      # raises on malformed text / capacity
         if rec.cursor_after != sh.V or rec.stats.n_kept != sh.V:
             raise AssertionError(f"{sh.contig}: kept {rec.stats.n_kept} of {sh.V} records")
+        lay = sh.layout
+        if sh.res.P is not None:
+            if rec.reserved:
+                raise AssertionError(f"{sh.contig}: {rec.reserved} calls beyond 0 / 1 / missing in biallelic text")
+            G = ctx.planes_expand(sh.res)
+            z = lambda n, dt: torch.zeros(n, dtype=dt, device=ctx.device)
+            r8 = dev.EncodeResult(z(G.numel(), torch.uint8), lay, z(lay.v_capacity, torch.int32), None, z(lay.v_capacity, torch.uint8),
+                                  z(lay.v_capacity, torch.uint8), 0, {})
+            c8 = z(1, torch.int64)
+            ctx.encode_text_async(sh.text, S, r8, c8, max_lines=sh.max_lines, region=sh.contig).wait()
+            ctx.pad_tail_cursor(r8, c8)
+            if not torch.equal(r8.G, G) or not torch.equal(r8.start, sh.res.start):
+                raise AssertionError(f"{sh.contig}: the expanded planes differ from the int8 encoder's matrix")
+            rep["shards_cross_checked_int8"] += 1
+            del r8
+        else:
+            G = sh.res.G
         back, bad = ctx.decompress(sh.dst, sh.off, sh.n_chunks, sh.chunk_nbytes, typesize=2, blocksize=blocksize)
-        if bad or not torch.equal(back, sh.res.G):
+        if bad or not torch.equal(back, G):
             raise AssertionError(f"{sh.contig}: decoded chunks differ from the genotype matrix ({bad} chunks flagged)")
         rep["chunks_decoded_gpu"] += sh.n_chunks
         del back
         vs = np.unique(np.concatenate([[0, sh.V - 1], rng.integers(0, sh.V, 62)]))
-        lay = sh.layout
-        g = sh.res.G.view(torch.int8).view(lay.v_capacity // lay.vc, -(-S // lay.sc), lay.sc, lay.vc, 2)
+        g = G.view(torch.int8).view(lay.v_capacity // lay.vc, -(-S // lay.sc), lay.sc, lay.vc, 2)
         for v in vs:
             want = synth.genotype_bits(sh.seed, int(v), 1, S, sh.tab["thr"][v:v + 1])[0]          # [S, 2]
             got = g[int(v) // lay.vc, :, :, int(v) % lay.vc, :].reshape(-1, 2)[:S].cpu().numpy()
             if not np.array_equal(got, want.astype(np.int8)):
                 raise AssertionError(f"{sh.contig}: variant {v} differs from the generator's genotypes")
         rep["variants_sampled"] += len(vs)
-    for sh, k in ((shards[0], 0), (shards[-1], shards[-1].n_chunks - 1)):
+        k = (si * 37) % sh.n_chunks if si else 0
+        if si == len(shards) - 1:
+            k = sh.n_chunks - 1
         off = sh.off[k:k + 2].cpu().numpy()
         chunk = sh.dst[int(off[0]):int(off[1])].cpu().numpy()
-        raw = sh.res.G[k * sh.chunk_nbytes:(k + 1) * sh.chunk_nbytes].cpu().numpy()
+        raw = G[k * sh.chunk_nbytes:(k + 1) * sh.chunk_nbytes].cpu().numpy()
         if not np.array_equal(oracle.blosc_decompress(chunk), raw):
             raise AssertionError(f"{sh.contig}: chunk {k} does not decode (oracle) to the matrix bytes")
         rep["chunks_decoded_oracle"] += 1
+        del G
     rep["ok"] = True
     return rep
 
@@ -487,6 +523,11 @@ def main():
         "index": text_bytes, "fixed": 0, "encode": sum(sh.V * 4 * S for sh in shards) + g_bytes,
         "lz4": g_bytes + comp_bytes, "frame": 2 * comp_bytes,
     }
+    planes = args.intermediate == "planes"
+    p_bytes = sum(sh.res.P.numel() for sh in shards) if planes else 0
+    # what the kernels of this build actually move (planes step: the matrix crosses HBM as 2 bits per allele)
+    moved = {"encode": sum(sh.V * 4 * S for sh in shards) + (p_bytes if planes else g_bytes),
+             "lz4": (p_bytes if planes else g_bytes) + comp_bytes}
     # dominant kernel stage = largest share of device time
     dom = max((k for k in stages_serial if k in alg), key=lambda k: stages_serial[k]["ms"])
     dom_ms_per_launch = stages[dom]["ms"] / max(stages[dom]["launches"], 1)
@@ -511,11 +552,13 @@ def main():
     # step, over the step time, over the HBM peak
     b_whole = text_bytes + g_bytes + g_bytes + comp_bytes
     step_s = dt_max / args.steps
-    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_bitplanes", "encode": "k_encode_tiles", "index": "k_index_newlines",
+    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_bitplanes", "encode": "k_encode_planes" if planes else "k_encode_tiles", "index": "k_index_newlines",
                                        "frame": "k_frame_write"}.get(dom, dom),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
             "bytes_per_launch": dom_bytes_per_launch, "ms_per_launch": dom_ms_per_launch,
+            "bytes_definition": "SURVEY 8d per-variant figure x variants per launch (lz4: 2 S read + 2 S / r written; encode: 4 S + 2 S)",
+            "moved_bytes_per_launch": moved.get(dom, alg[dom]) / max(len(shards), 1),
             "whole_path": {"bytes_per_step": b_whole, "GBps": b_whole / step_s / 1e9, "frac": b_whole / step_s / 1e9 / HBM_PEAK_GBS,
                            "definition": "SURVEY 8d: V (F + 6 S) + V' 2 S (1 + 1/r) over the step time over 8 TB/s"}}
     if dom == "lz4" and streams is not None and not args.cu_split and not args.lz4_priority:
@@ -549,6 +592,7 @@ def main():
                    "compression_ratio": g_bytes / max(comp_bytes, 1),
                    "parallelism": f"per-chromosome shards x{world}, no collective"
                                   + (f" ({backend}: {world} ranks on {n_dev} GPU: a rehearsal, not a scaling measurement)" if shared_gpu else ""),
+                   "intermediate": "bit planes, 2 bits per allele (include/hhgt.h)" if planes else "int8 matrix",
                    "streams": 1 if args.no_overlap else 2,
                    "compress_stream": None if args.no_overlap else "CU mask: 3/4 of the chip (hhgt_stream_create)"},
         "roofline": roof,

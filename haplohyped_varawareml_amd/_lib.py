@@ -94,8 +94,8 @@ def load():
                                                 vp, vp]
     L.hhgt_pad_tail_planes_cursor.argtypes = [vp, C.POINTER(Layout), vp, vp, vp]
     L.hhgt_pad_tail_planes.argtypes = [vp, C.POINTER(Layout), u64, u64, u64, vp, vp]
-    L.hhgt_compress_planes.argtypes = [vp, vp, vp, u64, u64, i32, vp, u64, vp, C.POINTER(u64), vp]
-    L.hhgt_planes_expand.argtypes = [vp, vp, vp, u64, vp, vp]
+    L.hhgt_compress_planes.argtypes = [vp, C.POINTER(Layout), vp, vp, C.c_uint32, C.c_uint32, i32, vp, u64, vp, C.POINTER(u64), vp]
+    L.hhgt_planes_expand.argtypes = [vp, C.POINTER(Layout), vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     L.hhgt_encode_result_status.argtypes = [vp]
     L.hhgt_pad_tail_cursor.argtypes = [vp, C.POINTER(Layout), vp, vp, vp]
     L.hhgt_encode_chrom_runs.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(C.c_uint32)]

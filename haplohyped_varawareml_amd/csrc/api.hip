@@ -484,6 +484,19 @@ extern "C" uint64_t hhgt_planes_bytes(const hhgt_layout *lay)
     return (uint64_t)L.n_sc * L.Sc * L.v_capacity / 2ull;
 }
 
+// columns [col0, col0 + n_cols) of a plane buffer: checks and geometry shared by compress and expand
+static int planes_columns(const hhgt_layout *lay, uint32_t col0, uint32_t n_cols, LayoutDev *L, PlanesGeom *pg)
+{
+    TRY(make_layout(lay, L));
+    TRY(planes_check_layout(*L));
+    if ((uint64_t)col0 + n_cols > L->v_capacity / L->Vc) {
+        hhgt_set_error("planes: columns [%u, %u) outside the layout's %llu", col0, col0 + n_cols, (unsigned long long)(L->v_capacity / L->Vc));
+        return HHGT_ERR_ARG;
+    }
+    *pg = planes_geom(*L, col0);
+    return HHGT_OK;
+}
+
 static int encode_async_impl(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region, const hhgt_layout *lay,
                              uint64_t *d_cursor, uint32_t max_lines, void *d_G, void *d_P, bool planes, uint32_t *d_start,
                              uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_result *h_result, void *stream)
@@ -559,12 +572,16 @@ extern "C" int hhgt_pad_tail_planes_cursor(hhgt_ctx *c, const hhgt_layout *lay, 
     return launch_pad_tail_planes_cursor(L, d_cursor, static_cast<uint8_t *>(d_P), reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int hhgt_planes_expand(hhgt_ctx *c, const void *d_P, const void *d_G, uint64_t n_blocks, void *d_out, void *stream)
+extern "C" int hhgt_planes_expand(hhgt_ctx *c, const hhgt_layout *lay, const void *d_P, const void *d_G, uint32_t col0, uint32_t n_cols,
+                                  void *d_out, void *stream)
 {
     if (!c || !d_P || !d_out) return HHGT_ERR_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    if (n_blocks == 0) return HHGT_OK;
-    return launch_planes_expand(static_cast<const uint8_t *>(d_P), static_cast<const uint8_t *>(d_G), n_blocks,
+    LayoutDev L;
+    PlanesGeom pg;
+    TRY(planes_columns(lay, col0, n_cols, &L, &pg));
+    if (n_cols == 0) return HHGT_OK;
+    return launch_planes_expand(L, static_cast<const uint8_t *>(d_P), static_cast<const uint8_t *>(d_G), col0, n_cols,
                                 static_cast<uint8_t *>(d_out), reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -726,7 +743,7 @@ extern "C" uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes
 
 // shuffle + LZ4 + framing of n_chunks chunks that exist as int8 bytes (d_src) or as bit planes (d_planes; d_src then only
 // holds the bytes of calls beyond 0 / 1 / missing and may be NULL)
-static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, uint64_t n_chunks, uint64_t chunk_nbytes,
+static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes,
                          int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
                          uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream)
 {
@@ -755,7 +772,7 @@ static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, u
     TRY(c->fr_flags.ensure((size_t)n_chunks * 4));
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
-        TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), n_chunks, chunk_nbytes, typesize,
+        TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), pg, n_chunks, chunk_nbytes, typesize,
                               blocksize, c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel,
                               c->lz_marked.as<uint32_t>() + 1, c->lz_marked.as<uint32_t>(), st));
         t.stop();
@@ -763,7 +780,7 @@ static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, u
     {
         StageTimer t(c, st, HHGT_STAGE_FRAME);
         TRY(launch_frame(c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(),
-                         static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), n_chunks, chunk_nbytes, typesize,
+                         static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), pg, n_chunks, chunk_nbytes, typesize,
                          blocksize, format, c->fr_bsize.as<uint32_t>(), c->fr_csize.as<uint64_t>(), static_cast<uint8_t *>(d_dst),
                          dst_cap, d_chunk_off, c->fr_flags.as<uint32_t>(), st));
         t.stop();
@@ -787,20 +804,23 @@ extern "C" int hhgt_compress_chunks(hhgt_ctx *c, const void *d_src, uint64_t n_c
                                     uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream)
 {
     if (!d_src) return HHGT_ERR_ARG;
-    return compress_impl(c, d_src, nullptr, n_chunks, chunk_nbytes, typesize, blocksize, format, d_dst, dst_cap, d_chunk_off,
-                         total_bytes, stream);
+    return compress_impl(c, d_src, nullptr, PlanesGeom{0, 0, 0, 0}, n_chunks, chunk_nbytes, typesize, blocksize, format, d_dst, dst_cap,
+                         d_chunk_off, total_bytes, stream);
 }
 
-extern "C" int hhgt_compress_planes(hhgt_ctx *c, const void *d_P, const void *d_G, uint64_t n_chunks, uint64_t chunk_nbytes,
+extern "C" int hhgt_compress_planes(hhgt_ctx *c, const hhgt_layout *lay, const void *d_P, const void *d_G, uint32_t col0, uint32_t n_cols,
                                     int format, void *d_dst, uint64_t dst_cap, uint64_t *d_chunk_off, uint64_t *total_bytes,
                                     void *stream)
 {
-    if (!d_P) return HHGT_ERR_ARG;
-    if (chunk_nbytes % 8192ull) {
-        hhgt_set_error("compress_planes: chunk_nbytes (%llu) must be a multiple of the 8192-byte block", (unsigned long long)chunk_nbytes);
-        return HHGT_ERR_ARG;
-    }
-    return compress_impl(c, d_G, d_P, n_chunks, chunk_nbytes, 2, 8192, format, d_dst, dst_cap, d_chunk_off, total_bytes, stream);
+    if (!c || !d_P) return HHGT_ERR_ARG;
+    LayoutDev L;
+    PlanesGeom pg;
+    TRY(planes_columns(lay, col0, n_cols, &L, &pg));
+    const uint64_t chunk_nbytes = (uint64_t)L.Sc * L.Vc * 2ull, col_bytes = chunk_nbytes * L.n_sc;
+    // the chunks of columns col0.. in the int8 matrix (it only backs the calls beyond 0 / 1 / missing)
+    const uint8_t *g = d_G ? static_cast<const uint8_t *>(d_G) + (uint64_t)col0 * col_bytes : nullptr;
+    return compress_impl(c, g, d_P, pg, (uint64_t)n_cols * L.n_sc, chunk_nbytes, 2, 8192, format, d_dst, dst_cap, d_chunk_off, total_bytes,
+                         stream);
 }
 
 extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)

@@ -79,6 +79,43 @@ struct LayoutDev {
     uint32_t pad_;
 };
 
+// ---- bit-plane form of the matrix (include/hhgt.h "Bit-plane form"): tile-major ----------------------------------------
+// A chunk column (Vc variants x S_pad padded sample rows) is cut into tiles of PL_TILE variants; a tile holds, per kind-plane
+// kp (0: ONE hap 0, 1: ONE hap 1, 2: EXC hap 0, 3: EXC hap 1) and sample row r, one 32-byte piece (bit i = variant i of the
+// tile): P[column slot][tile][kp][row][32 B].  The encoder's workgroup (256 rows x one tile) therefore writes four
+// contiguous 8 KiB runs — the first version of this path wrote row-major planes, 32-byte pieces 2 KiB apart, and spent
+// 40 % of its time on those partial-line writes — and a compressor wave gathers the 16 pieces of its 4096-variant plane.
+#define PL_TILE 256u
+struct PlanesGeom {
+    uint32_t S_pad;   // padded sample rows per chunk column (n_sc * Sc)
+    uint32_t bpr;     // Blosc blocks (4096 variants) per sample row of a column: Vc / 4096
+    uint32_t tpc;     // tiles per column: Vc / PL_TILE = 16 * bpr
+    uint32_t col0;    // first column slot a compress / expand call works on
+};
+static inline __host__ __device__ uint64_t planes_piece(const PlanesGeom &g, uint64_t col, uint32_t tile, uint32_t kp, uint32_t row)
+{
+    return ((((col * g.tpc + tile) * 4ull + kp) * g.S_pad) + row) * 32ull;
+}
+static inline __host__ __device__ PlanesGeom planes_geom(const LayoutDev &L, uint32_t col0)
+{
+    PlanesGeom g;
+    g.S_pad = L.n_sc * L.Sc;
+    g.bpr = (uint32_t)(L.Vc >> 12);
+    g.tpc = (uint32_t)(L.Vc / PL_TILE);
+    g.col0 = col0;
+    return g;
+}
+// block `id` of a compress call (G's block order relative to column col0) -> column slot, sample row, block in the row
+static inline __host__ __device__ void planes_block(const PlanesGeom &g, uint64_t id, uint64_t *col, uint32_t *row, uint32_t *bi)
+{
+    const uint64_t per_col = (uint64_t)g.S_pad * g.bpr;
+    const uint64_t c = id / per_col;
+    const uint32_t rem = (uint32_t)(id - c * per_col);
+    *col = g.col0 + c;
+    *row = rem / g.bpr;
+    *bi = rem - (rem / g.bpr) * g.bpr;
+}
+
 // workspace buffer that only grows
 struct DevBuf {
     void *p = nullptr;
@@ -171,7 +208,7 @@ int launch_encode_planes(const uint8_t *d_text, uint64_t n, const uint32_t *k_so
                          uint32_t *redo_list, uint32_t *redo_flag, DevCounters *d_cnt, hipStream_t st);
 int launch_pad_tail_planes(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, uint8_t *d_P, hipStream_t st);
 int launch_pad_tail_planes_cursor(LayoutDev lay, const uint64_t *d_cursor, uint8_t *d_P, hipStream_t st);
-int launch_planes_expand(const uint8_t *d_P, const uint8_t *d_G, uint64_t n_blocks, uint8_t *d_out, hipStream_t st);
+int launch_planes_expand(LayoutDev lay, const uint8_t *d_P, const uint8_t *d_G, uint32_t col0, uint32_t n_cols, uint8_t *d_out, hipStream_t st);
 int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, int8_t *d_G,
                     hipStream_t st);
 // zero [*d_cursor, round_up(*d_cursor, Vc)) of the cursor's chunk column and the sample padding rows of that column
@@ -181,15 +218,15 @@ int launch_pad_tail_cursor(LayoutDev lay, const uint64_t *d_cursor, int8_t *d_G,
 size_t lz4_slot_bytes(int neblock);
 // d_planes != NULL: the chunks exist as bit planes (hhgt.h "Bit-plane form"); d_src then only supplies the bytes of calls
 // beyond 0 / 1 / missing and may be NULL
-int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
                       int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
                       uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st);
 // lz4bits.hip: typesize 2, 8 KiB blocks; streams it cannot code get csize = 0xFFFFFFFF
-int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
                          uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st);
 // frame.hip
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
-                 uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
+                 PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
                  uint32_t *d_bstart, uint64_t *d_chunk_csize, uint8_t *d_dst, uint64_t dst_cap,
                  uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st);
 int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_chunks, uint64_t chunk_nbytes,

@@ -192,20 +192,33 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 // two BITS per allele instead of a byte (include/hhgt.h "Bit-plane form"): ONE (allele 1, or missing) and EXC (anything
 // but 0 / 1), so what crosses HBM between the two halves of the path is S/2 bytes per variant each way instead of 2 S.
 //
-// A 256-thread workgroup owns 512 variants x 256 samples: 512 variants so that every (sample, plane) leaves as 64
-// contiguous bytes; wave w reads lines [128 w, 128 w + 128) of the tile, 8 lines (1 KiB each, 16 B per lane = 4
-// samples) in flight while the previous 8 are packed.  Packing is SWAR on the field dword "a|b\t": (x & 0x00010001)
-// holds the two allele bits, shifted by the line number they accumulate into a register whose low half is haplotype 0
-// and whose high half is haplotype 1 over 16 lines; one xor/or chain per line tells whether all four fields of the lane
-// were "[01]|[01]\t".  Only a group of 16 lines in which some lane saw anything else (a missing call, '/', a third
-// allele) is parsed again field by field.  Per 32 lines a lane holds one dword per (sample, plane, kind): 16
-// conflict-free ds_write_b32 into a 64 KiB image [kind][plane][sample][64 B]; after one barrier the image leaves in
-// 16-byte pieces, four lanes per 64-byte row.  The tile that straddles the append position merges with the bits the
-// previous call wrote.
-// HBM roofline: algorithmic bytes per variant = 4 S read + S/2 written.
-#define PT_V 512
-#define PT_LW 128
-#define PT_G 8
+// A 256-thread workgroup owns one plane tile (PL_TILE = 256 variants) of 256 samples; wave w reads lines [64 w, 64 w + 64)
+// of the tile in groups of lines (1 KiB each, 16 B per lane = 4 samples) whose loads are in flight together; where a
+// group's line starts come from: pl_load_step.  Packing is SWAR on the field dword "a|b\t": (x & 0x00010001) holds the
+// two allele bits, shifted by the line number they accumulate into a register whose low half is haplotype 0 and whose
+// high half is haplotype 1 over 16 lines; one xor/or chain per line tells whether all four fields of the lane were
+// "[01]|[01]\t" (pl_pack_group: what happens otherwise).  Per 32 lines a lane holds one dword per (sample, plane, kind):
+// 16 ds_write_b32 into a 32 KiB image [kind][plane][sample][32 B]; after one barrier the image leaves as four contiguous
+// 8 KiB runs — the planes are TILE-MAJOR in HBM (common.h) for exactly that.  The tile that straddles the append position
+// merges with the bits the previous call wrote.
+// HBM roofline: algorithmic bytes per variant = 4 S read + S/2 written.  What bounds it in practice: the 16-byte loads
+// start at the byte where a line's sample columns start, and a wave-load whose lanes are not dword-aligned is worth
+// ~20 % less (tools/micro/strided_read.hip: 6.4 -> 5.1 TB/s).
+#define PT_V 256           // = PL_TILE
+#define PT_ROWDW (PT_V / 32)                    // dwords per image row
+#ifndef PT_NW
+#define PT_NW 4            // waves per workgroup
+#endif
+#define PT_LW (PT_V / PT_NW)   // lines per wave
+#ifndef PT_G
+#define PT_G 8             // lines per load group
+#endif
+#ifndef PT_DB
+#define PT_DB 1            // the next group's loads are issued before a group is packed
+#endif
+#ifndef PT_WGS
+#define PT_WGS 4           // waves per SIMD the register allocation leaves room for (= workgroups per CU)
+#endif
 #define PT_C 0x09307C30u   // "0|0\t"
 
 struct PlGroup {
@@ -213,71 +226,96 @@ struct PlGroup {
     uint32_t lvalid;   // bit j: line j of the group is a kept fixed-width line (wave-uniform)
 };
 
+// the line table of 32 lines at once: lane j holds soff / meta of line kb + j (meta = 0 beyond the batch), so that a
+// load group needs no scalar loads (the first version paid two dependent s_load round trips in front of every line)
+struct PlStep {
+    uint32_t soff, meta;
+};
+
+__device__ __forceinline__ PlStep pl_load_step(const uint32_t *__restrict__ k_soff, const uint32_t *__restrict__ k_meta, long long kb,
+                                               uint32_t n_kept, uint32_t lane)
+{
+    PlStep t;
+    const long long k = kb + (long long)(lane & 31u);
+    const bool valid = k >= 0 && k < (long long)n_kept;
+    t.soff = valid ? k_soff[k] : 0u;
+    t.meta = valid ? k_meta[k] : 0u;
+    return t;
+}
+
+// the 16 bytes (four sample fields) of one line that this lane owns
 template <bool EDGE>
-__device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__restrict__ text, uint64_t n,
-                                              const uint32_t *__restrict__ k_soff, const uint32_t *__restrict__ k_meta,
-                                              long long kbase, uint32_t n_kept, uint32_t ls, uint32_t nval, uint32_t last_q)
+__device__ __forceinline__ uint4 pl_load_line(const uint8_t *__restrict__ text, uint64_t n, uint32_t soff, uint32_t ls, uint32_t nval,
+                                              uint32_t last_q)
+{
+    uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
+    const uint64_t off = (uint64_t)soff + 4ull * ls;
+    if (!EDGE) {   // every lane owns four samples in front of the line's last one: the 16 bytes lie inside the line
+        u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
+        v = make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+        if (nval == 4u && off + 16ull <= n) {
+            u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
+            v = make_uint4(t.x, t.y, t.z, t.w);
+        } else if (nval) {
+            uint32_t d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t x = FILL_FIELD;
+                if ((uint32_t)q < nval) {
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        uint64_t idx = off + (uint64_t)(q * 4 + bb);
+                        uint32_t c = idx < n ? text[idx] : (uint32_t)'\t';
+                        x = (x & ~(0xFFu << (bb * 8))) | (c << (bb * 8));
+                    }
+                }
+                d[q] = x;
+            }
+            v = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        // the last sample of a line is terminated by the line end (LF_FAST pinned where it ends)
+        if (last_q == 0u) v.x = (v.x & 0x00FFFFFFu) | 0x09000000u;
+        if (last_q == 1u) v.y = (v.y & 0x00FFFFFFu) | 0x09000000u;
+        if (last_q == 2u) v.z = (v.z & 0x00FFFFFFu) | 0x09000000u;
+        if (last_q == 3u) v.w = (v.w & 0x00FFFFFFu) | 0x09000000u;
+    }
+    return v;
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__restrict__ text, uint64_t n, const PlStep &stp, const int j0,
+                                              uint32_t ls, uint32_t nval, uint32_t last_q)
 {
     uint32_t lv = 0;
 #pragma unroll
     for (int j = 0; j < PT_G; ++j) {
-        const long long k = kbase + j;
-        bool valid = k >= 0 && k < (long long)n_kept;
-        uint32_t meta = 0, soff = 0;
-        if (valid) {
-            meta = k_meta[k];
-            soff = k_soff[k];
-        }
-        valid = valid && (meta & LF_FAST);
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)stp.meta, j0 + j);
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)stp.soff, j0 + j);
         uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
-        if (valid) {
+        if (meta & LF_FAST) {   // (wave-uniform)
             lv |= 1u << j;
-            const uint64_t off = (uint64_t)soff + 4ull * ls;
-            if (!EDGE) {   // every lane owns four samples in front of the line's last one: the 16 bytes lie inside the line
-                u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
-                v = make_uint4(t.x, t.y, t.z, t.w);
-            } else if (nval == 4u && off + 16ull <= n) {
-                u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
-                v = make_uint4(t.x, t.y, t.z, t.w);
-            } else if (nval) {
-                uint32_t d[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t x = FILL_FIELD;
-                    if ((uint32_t)q < nval) {
-#pragma unroll
-                        for (int bb = 0; bb < 4; ++bb) {
-                            uint64_t idx = off + (uint64_t)(q * 4 + bb);
-                            uint32_t c = idx < n ? text[idx] : (uint32_t)'\t';
-                            x = (x & ~(0xFFu << (bb * 8))) | (c << (bb * 8));
-                        }
-                    }
-                    d[q] = x;
-                }
-                v = make_uint4(d[0], d[1], d[2], d[3]);
-            }
-            if (EDGE) {   // the last sample of a line is terminated by the line end (LF_FAST pinned where it ends)
-                if (last_q == 0u) v.x = (v.x & 0x00FFFFFFu) | 0x09000000u;
-                if (last_q == 1u) v.y = (v.y & 0x00FFFFFFu) | 0x09000000u;
-                if (last_q == 2u) v.z = (v.z & 0x00FFFFFFu) | 0x09000000u;
-                if (last_q == 3u) v.w = (v.w & 0x00FFFFFFu) | 0x09000000u;
-            }
+            v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
         }
         gr.raw[j] = v;
     }
     gr.lvalid = lv;
 }
 
-// 16 lines -> per sample q: one[q] / exc[q], bit j (haplotype 0) and bit 16 + j (haplotype 1) for line j.
-// Three levels.  (1) every field of every lane is "[01]|[01]\t": 14 vector instructions per line.  (2) some lane saw
-// something else: the group again with every field classified over the alphabet {0, 1, .} x {|, /} — still branch-free
-// SWAR on the field dword, x ^ "0|0\t": an allele byte must be 0x00, 0x01 or 0x1E ('.'), bit 4 of it is the EXC bit and
-// bit 0 | bit 4 the ONE bit; the separator byte 0x00 or 0x53 ('/'), the terminator 0x00.  (3) a field outside that
-// alphabet (a third allele, a multi-digit index, anything malformed) contributes zero bits and sends its line to the
-// variable-width kernel, which sets the bits of the whole line (idempotent for the fields that were fine here).
+// PT_G lines -> per sample q: one[q] / exc[q], bit sh + j (haplotype 0) and bit 16 + sh + j (haplotype 1) for line j.
+// Three levels.  (1) every field of every lane is "[01]|[01]\t": ~14 vector instructions per line, unrolled.  (2) some
+// lane saw something else: the group again, line by line in a rolled loop that reads the (cache-hot) line once more and
+// classifies every field over the alphabet {0, 1, .} x {|, /} — branch-free SWAR on the field dword, x ^ "0|0\t": an
+// allele byte must be 0x00, 0x01 or 0x1E ('.'), bit 4 of it is the EXC bit and bit 0 | bit 4 the ONE bit; the separator
+// byte 0x00 or 0x53 ('/'), the terminator 0x00.  (3) a field outside that alphabet (a third allele, a multi-digit index,
+// anything malformed) contributes zero bits and sends its line to the variable-width kernel, which sets the bits of the
+// whole line (idempotent for the fields that were fine here).  Keeping (2) rolled and out of the registers of (1) is
+// what lets four workgroups share a CU.
+template <bool EDGE>
 __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, uint32_t (&one)[4], uint32_t (&exc)[4], long long kbase,
-                                              uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag, DevCounters *cnt,
-                                              uint32_t lane)
+                                              const uint8_t *__restrict__ text, uint64_t n, const PlStep &stp, const int j0, uint32_t ls,
+                                              uint32_t nval, uint32_t last_q, uint32_t *__restrict__ redo_list,
+                                              uint32_t *__restrict__ redo_flag, DevCounters *cnt, uint32_t lane)
 {
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, bad = 0;
 #pragma unroll
@@ -293,9 +331,13 @@ __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, u
         one[0] |= a0, one[1] |= a1, one[2] |= a2, one[3] |= a3;
         return;
     }
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < PT_G; ++j) {
-        const uint32_t xs[4] = {gr.raw[j].x, gr.raw[j].y, gr.raw[j].z, gr.raw[j].w};
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)stp.meta, j0 + j);
+        if (!(meta & LF_FAST)) continue;
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)stp.soff, j0 + j);
+        const uint4 v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
+        const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
         uint32_t hard = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -311,14 +353,12 @@ __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, u
             exc[q] |= (e2 & keep) << (sh + j);
             hard |= off;
         }
-        if ((gr.lvalid >> j) & 1u) {
-            const unsigned long long bm = __builtin_amdgcn_ballot_w64(hard != 0u);
-            if (bm != 0ull && lane == 0) {
-                const uint32_t k = (uint32_t)(kbase + j);
-                if (atomicExch(&redo_flag[k], 1u) == 0u) {
-                    unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
-                    redo_list[slot] = k;
-                }
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(hard != 0u);
+        if (bm != 0ull && lane == 0) {
+            const uint32_t k = (uint32_t)(kbase + j);
+            if (atomicExch(&redo_flag[k], 1u) == 0u) {
+                unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
+                redo_list[slot] = k;
             }
         }
     }
@@ -329,12 +369,12 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
                                                    const uint32_t *__restrict__ k_meta, uint64_t v_base, uint32_t n_kept,
                                                    const LayoutDev &lay, uint8_t *__restrict__ P, int8_t *__restrict__ G,
                                                    uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
-                                                   DevCounters *cnt, uint32_t *img)
+                                                   DevCounters *cnt, uint32_t *img, uint32_t band0)
 {
     const uint64_t gv0 = (v_base / PT_V + blockIdx.x) * (uint64_t)PT_V;   // first global column of the tile
     const long long k0 = (long long)gv0 - (long long)v_base;              // batch-local kept index of it
     if (k0 >= (long long)n_kept || (!lay.ring && gv0 >= lay.v_capacity)) return;
-    const uint32_t s0 = blockIdx.y * TILE_S;
+    const uint32_t s0 = (blockIdx.y + band0) * TILE_S;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t S = lay.S;
@@ -343,49 +383,71 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
     const uint32_t last_q = (S - 1u >= ls && S - 1u < ls + 4u) ? S - 1u - ls : 4u;
     const long long kw = k0 + (long long)(w * PT_LW);
 
-    PlGroup A, B;
-    pl_load_group<EDGE>(A, text, n, k_soff, k_meta, kw, n_kept, ls, nval, last_q);
+    constexpr int NG = 32 / PT_G;   // load groups per 32 lines
+    PlStep nxt = pl_load_step(k_soff, k_meta, kw, n_kept, lane);
 #pragma unroll 1
-    for (int gp = 0; gp < PT_LW / 32; ++gp) {   // 32 lines = four groups of 8, the next group's loads in flight while one is packed
+    for (int gp = 0; gp < PT_LW / 32; ++gp) {   // 32 lines -> one dword per (kind, plane, sample)
         const long long kb = kw + (long long)(gp * 32);
-        uint32_t o0[4] = {0, 0, 0, 0}, e0[4] = {0, 0, 0, 0}, o1[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0};
-        pl_load_group<EDGE>(B, text, n, k_soff, k_meta, kb + 8, n_kept, ls, nval, last_q);
-        pl_pack_group(A, 0, o0, e0, kb, redo_list, redo_flag, cnt, lane);
-        pl_load_group<EDGE>(A, text, n, k_soff, k_meta, kb + 16, n_kept, ls, nval, last_q);
-        pl_pack_group(B, 8, o0, e0, kb + 8, redo_list, redo_flag, cnt, lane);
-        pl_load_group<EDGE>(B, text, n, k_soff, k_meta, kb + 24, n_kept, ls, nval, last_q);
-        pl_pack_group(A, 0, o1, e1, kb + 16, redo_list, redo_flag, cnt, lane);
-        if (gp + 1 < PT_LW / 32) pl_load_group<EDGE>(A, text, n, k_soff, k_meta, kb + 32, n_kept, ls, nval, last_q);
-        pl_pack_group(B, 8, o1, e1, kb + 24, redo_list, redo_flag, cnt, lane);
-        // 32 lines of this lane's four samples: one dword per (kind, plane, sample).  Image row (kind * 2 + plane) * 256
-        // + q * 64 + lane, 16 dwords; dword c of a row sits at c ^ (lane >> 2): the 64 lanes of a store hit 64 banks.
-        const uint32_t c = (w * 4u + (uint32_t)gp) ^ (lane >> 2);
+        const PlStep stp = nxt;
+        if (gp + 1 < PT_LW / 32) nxt = pl_load_step(k_soff, k_meta, kb + 32, n_kept, lane);
+        uint32_t o[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, e[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        // PT_SCHED(): the instruction scheduler may not move anything across — it would otherwise hoist the loads of all
+        // four groups of a step to its top (128 registers of text in flight per lane, and spills)
+#define PT_SCHED() __builtin_amdgcn_sched_barrier(0)
+#if PT_DB
+        PlGroup A, B;
+        pl_load_group<EDGE>(A, text, n, stp, 0, ls, nval, last_q);
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            pl_load_group<EDGE>(B, text, n, stp, (g + 1) * PT_G, ls, nval, last_q);
+            PT_SCHED();
+            pl_pack_group<EDGE>(A, (g * PT_G) & 15, o[(g * PT_G) >> 4], e[(g * PT_G) >> 4], kb + g * PT_G, text, n, stp, g * PT_G, ls, nval,
+                                last_q, redo_list, redo_flag, cnt, lane);
+            PT_SCHED();
+            if (g + 2 < NG) pl_load_group<EDGE>(A, text, n, stp, (g + 2) * PT_G, ls, nval, last_q);
+            PT_SCHED();
+            pl_pack_group<EDGE>(B, ((g + 1) * PT_G) & 15, o[((g + 1) * PT_G) >> 4], e[((g + 1) * PT_G) >> 4], kb + (g + 1) * PT_G, text, n,
+                                stp, (g + 1) * PT_G, ls, nval, last_q, redo_list, redo_flag, cnt, lane);
+            PT_SCHED();
+        }
+#else
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            PlGroup A;
+            pl_load_group<EDGE>(A, text, n, stp, g * PT_G, ls, nval, last_q);
+            PT_SCHED();
+            pl_pack_group<EDGE>(A, (g * PT_G) & 15, o[(g * PT_G) >> 4], e[(g * PT_G) >> 4], kb + g * PT_G, text, n, stp, g * PT_G, ls, nval,
+                                last_q, redo_list, redo_flag, cnt, lane);
+            PT_SCHED();
+        }
+#endif
+        // image row (kind * 2 + plane) * 256 + sample, 8 dwords; dword c of a row sits at c ^ ((lane >> 1) & 7)
+        const uint32_t c = (w * (uint32_t)(PT_LW / 32) + (uint32_t)gp) ^ ((lane >> 1) & 7u);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t r = ((uint32_t)q * 64u + lane) * 16u + c;
-            img[r] = __builtin_amdgcn_perm(o1[q], o0[q], 0x05040100u);             // ONE, haplotype 0
-            img[256u * 16u + r] = __builtin_amdgcn_perm(o1[q], o0[q], 0x07060302u);   // ONE, haplotype 1
-            img[512u * 16u + r] = __builtin_amdgcn_perm(e1[q], e0[q], 0x05040100u);   // EXC, haplotype 0
-            img[768u * 16u + r] = __builtin_amdgcn_perm(e1[q], e0[q], 0x07060302u);   // EXC, haplotype 1
+            const uint32_t r = (4u * lane + (uint32_t)q) * PT_ROWDW + c;
+            img[r] = __builtin_amdgcn_perm(o[1][q], o[0][q], 0x05040100u);                   // ONE, haplotype 0
+            img[256u * PT_ROWDW + r] = __builtin_amdgcn_perm(o[1][q], o[0][q], 0x07060302u);   // ONE, haplotype 1
+            img[512u * PT_ROWDW + r] = __builtin_amdgcn_perm(e[1][q], e[0][q], 0x05040100u);   // EXC, haplotype 0
+            img[768u * PT_ROWDW + r] = __builtin_amdgcn_perm(e[1][q], e[0][q], 0x07060302u);   // EXC, haplotype 1
         }
     }
     __syncthreads();
-    // image -> HBM: 1024 rows x 64 B, four lanes per row
+    // image -> HBM: per kind-plane the 256 rows are one contiguous 8 KiB run of the tile (tile-major planes, common.h)
     uint64_t vcol = gv0 / lay.Vc;
     const uint64_t vin = gv0 - vcol * lay.Vc;
     if (lay.ring) vcol %= lay.ring;
-    const uint64_t bpr = lay.Vc >> 12;                       // Blosc blocks per sample row of a chunk
-    const uint32_t piece = (uint32_t)((vin & 4095ull) >> 9);  // which 64 bytes of the block's planes
+    const PlanesGeom pg = planes_geom(lay, 0u);
+    const uint32_t tile = (uint32_t)(vin / PL_TILE);
     const uint32_t nkeep = k0 < 0 ? (uint32_t)(-k0) : 0u;     // leading columns that belong to the previous call
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const uint32_t pi = (uint32_t)it * 256u + threadIdx.x;
-        const uint32_t R = pi >> 2, sl = pi & 3u;
-        const uint32_t kp = R >> 8, q = (R >> 6) & 3u, l = R & 63u;
-        const uint32_t s = s0 + 4u * l + q;
+    for (int it = 0; it < 2048 / (64 * PT_NW); ++it) {
+        const uint32_t pi = (uint32_t)it * (64u * PT_NW) + threadIdx.x;   // 16-byte piece: kp * 512 + row * 2 + half
+        const uint32_t kp = pi >> 9, row = (pi >> 1) & 255u, half = pi & 1u;
+        const uint32_t s = s0 + row;
         if (s >= S) continue;
-        const uint32_t sw = l >> 2;
-        const uint4 t = reinterpret_cast<const uint4 *>(img)[R * 4u + (sl ^ (sw >> 2))];
+        const uint32_t sw = (row >> 3) & 7u;   // the writer's (lane >> 1) & 7: row = 4 lane + q
+        const uint4 t = reinterpret_cast<const uint4 *>(img)[(kp * 256u + row) * 2u + (half ^ (sw >> 2))];
         uint32_t d0 = t.x, d1 = t.y, d2 = t.z, d3 = t.w;
         if (sw & 1u) {
             uint32_t u = d0; d0 = d1; d1 = u;
@@ -395,22 +457,19 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
             uint32_t u = d0; d0 = d2; d2 = u;
             u = d1; d1 = d3; d3 = u;
         }
-        const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
-        const uint32_t sin = s - scol * lay.Sc;
-        const uint64_t blk = ((vcol * lay.n_sc + scol) * lay.Sc + sin) * bpr + (vin >> 12);
-        uint8_t *dst = P + blk * 2048ull + kp * 512u + piece * 64u + sl * 16u;
+        uint8_t *dst = P + planes_piece(pg, vcol, tile, kp, s) + half * 16u;
         if (nkeep) {   // (workgroup-uniform) the tile straddles the append position
-            const uint32_t b0 = sl * 128u;
+            const uint32_t b0 = half * 128u;
             if (b0 + 128u <= nkeep) continue;
             if (b0 < nkeep) {
                 const uint4 old = *reinterpret_cast<const uint4 *>(dst);
                 const uint32_t nb = nkeep - b0;   // 1..127 low bits stay
-                const uint32_t o[4] = {old.x, old.y, old.z, old.w};
+                const uint32_t ov[4] = {old.x, old.y, old.z, old.w};
                 uint32_t d[4] = {d0, d1, d2, d3};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint32_t km = nb >= 32u * (i + 1) ? 0xFFFFFFFFu : (nb <= 32u * i ? 0u : ((1u << (nb - 32u * i)) - 1u));
-                    d[i] = (o[i] & km) | (d[i] & ~km);
+                    d[i] = (ov[i] & km) | (d[i] & ~km);
                 }
                 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
             }
@@ -419,21 +478,20 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_encode_planes(const uint8_t *__restrict__ text, uint64_t n,
+// EDGE: the band of sample columns that holds the last sample (and lanes past it) reads with care; every other band
+// reads 16 bytes flat.  Two instantiations, two launches: the hot one does not carry the careful one's registers.
+template <bool EDGE>
+__global__ __launch_bounds__(64 * PT_NW, EDGE ? 2 : PT_WGS) void k_encode_planes(const uint8_t *__restrict__ text, uint64_t n,
                                                           const uint32_t *__restrict__ k_soff, const uint32_t *__restrict__ k_meta,
                                                           const uint64_t *__restrict__ d_cursor, LayoutDev lay,
                                                           uint8_t *__restrict__ P, int8_t *__restrict__ G,
                                                           uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
-                                                          DevCounters *cnt)
+                                                          DevCounters *cnt, uint32_t band0)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t img[1024 * 16];   // 64 KiB
+    __shared__ __attribute__((aligned(16))) uint32_t img[1024 * PT_ROWDW];   // 32 KiB
     const uint64_t v_base = *d_cursor;
     const uint32_t n_kept = (uint32_t)cnt->n_kept;
-    // the tile row that holds the last sample (and lanes past it) reads with care; every other tile reads 16 bytes flat
-    if (blockIdx.y + 1u == gridDim.y)
-        encode_planes_tile<true>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img);
-    else
-        encode_planes_tile<false>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img);
+    encode_planes_tile<EDGE>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, band0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -489,6 +547,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                                                         DevCounters *cnt)
 {
     const uint64_t v_base = *d_cursor;
+    const PlanesGeom pgeom = planes_geom(lay, 0u);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * 4u;
@@ -585,21 +644,22 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 if (!PLANES) {
                     *reinterpret_cast<uint16_t *>(G + goff) = (uint16_t)hv;
                 } else {
-                    const uint32_t bit = (uint32_t)(goff & 8191ull) >> 1;
-                    uint32_t *pw = reinterpret_cast<uint32_t *>(P + (goff >> 13) * 2048ull) + (bit >> 5);
+                    const uint32_t bit = (uint32_t)(vin % PL_TILE);
+                    const uint64_t kstride = (uint64_t)pgeom.S_pad * 8ull;   // dwords between the kind-planes of a tile
+                    uint32_t *pw = reinterpret_cast<uint32_t *>(P + planes_piece(pgeom, vcol, (uint32_t)(vin / PL_TILE), 0u, s)) + (bit >> 5);
                     const uint32_t mk = 1u << (bit & 31u);
                     const uint32_t h0 = hv & 0xFFu, h1 = (hv >> 8) & 0xFFu;
                     if (h0 == 1u || h0 == 0xF7u) atomicOr(pw, mk);
-                    if (h1 == 1u || h1 == 0xF7u) atomicOr(pw + 128, mk);
+                    if (h1 == 1u || h1 == 0xF7u) atomicOr(pw + kstride, mk);
                     if (h0 > 1u) {
-                        atomicOr(pw + 256, mk);
+                        atomicOr(pw + 2ull * kstride, mk);
                         if (h0 != 0xF7u) {
                             atomicAdd(&cnt->n_other, 1ull);
                             if (G) G[goff] = (int8_t)h0;
                         }
                     }
                     if (h1 > 1u) {
-                        atomicOr(pw + 384, mk);
+                        atomicOr(pw + 3ull * kstride, mk);
                         if (h1 != 0xF7u) {
                             atomicAdd(&cnt->n_other, 1ull);
                             if (G) G[goff + 1ull] = (int8_t)h1;
@@ -731,55 +791,60 @@ int launch_encode_planes(const uint8_t *d_text, uint64_t n, const uint32_t *k_so
     const uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
     // the append position is only known on the device: one tile more than the lines need covers any phase
     const uint64_t tiles_v = ((uint64_t)(PT_V - 1) + (uint64_t)n_lines_bound + (PT_V - 1)) / PT_V;
-    hipLaunchKernelGGL(k_encode_planes, dim3((uint32_t)tiles_v, tiles_s), dim3(256), 0, st, d_text, n, k_soff, k_meta, d_cursor,
-                       lay, d_P, d_G, redo_list, redo_flag, d_cnt);
+    if (tiles_s > 1)
+        hipLaunchKernelGGL(k_encode_planes<false>, dim3((uint32_t)tiles_v, tiles_s - 1), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta,
+                           d_cursor, lay, d_P, d_G, redo_list, redo_flag, d_cnt, 0u);
+    hipLaunchKernelGGL(k_encode_planes<true>, dim3((uint32_t)tiles_v, 1), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta, d_cursor,
+                       lay, d_P, d_G, redo_list, redo_flag, d_cnt, tiles_s - 1);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
 
 // -------------------------------------------------------------------------------------------------
 // planes: zero the bits of variants [c0, Vc) of padded sample rows [r0, r1) of chunk columns vcol0 + blockIdx.z
-// (rows >= S: the whole row).  grid.x = Blosc blocks per sample row, 128 threads = the 128 dwords of a plane.
-__device__ __forceinline__ void zero_planes_row(const LayoutDev &lay, uint64_t vcol, uint32_t r, uint64_t c0, uint8_t *__restrict__ P)
+// (tile-major planes: per tile and kind-plane the rows' 32-byte pieces are contiguous).  grid.x walks the tiles of the
+// column, grid.y groups of 32 rows; a thread owns one dword of one row's piece, for the four kind-planes.
+__device__ __forceinline__ void zero_planes_rows(const LayoutDev &lay, uint64_t vcol, uint32_t r0, uint32_t r1, uint64_t c0, uint32_t S,
+                                                 uint8_t *__restrict__ P)
 {
-    const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (r >> lay.sc_log2);
-    const uint32_t sin = r - scol * lay.Sc;
-    const uint64_t bpr = lay.Vc >> 12;
-    for (uint64_t b = blockIdx.x; b < bpr; b += gridDim.x) {
-        const uint64_t lo = b * 4096ull + 32ull * threadIdx.x;   // first variant of this thread's dword
-        if (lo + 32ull <= c0) continue;
-        const uint32_t keep = lo >= c0 ? 0u : ((1u << (uint32_t)(c0 - lo)) - 1u);
-        uint32_t *p = reinterpret_cast<uint32_t *>(P + (((vcol * lay.n_sc + scol) * lay.Sc + sin) * bpr + b) * 2048ull) + threadIdx.x;
+    const PlanesGeom pg = planes_geom(lay, 0u);
+    const uint32_t r = r0 + blockIdx.y * 32u + (threadIdx.x >> 3), dw = threadIdx.x & 7u;
+    if (r >= r1) return;
+    const uint64_t from = r < S ? c0 : 0ull;   // sample padding rows: the whole row
+    for (uint32_t t = blockIdx.x; t < pg.tpc; t += gridDim.x) {
+        const uint64_t lo = (uint64_t)t * PL_TILE + 32ull * dw;   // first variant of this thread's dword
+        if (lo + 32ull <= from) continue;
+        const uint32_t keep = lo >= from ? 0u : ((1u << (uint32_t)(from - lo)) - 1u);
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) p[128 * kp] = keep ? (p[128 * kp] & keep) : 0u;
+        for (uint32_t kp = 0; kp < 4u; ++kp) {
+            uint32_t *p = reinterpret_cast<uint32_t *>(P + planes_piece(pg, vcol, t, kp, r)) + dw;
+            *p = keep ? (*p & keep) : 0u;
+        }
     }
 }
 
-__global__ __launch_bounds__(128) void k_zero_planes_rect(LayoutDev lay, uint64_t vcol0, uint32_t r0, uint32_t r1, uint64_t c0,
+__global__ __launch_bounds__(256) void k_zero_planes_rect(LayoutDev lay, uint64_t vcol0, uint32_t r0, uint32_t r1, uint64_t c0,
                                                           uint8_t *__restrict__ P)
 {
-    const uint32_t r = r0 + blockIdx.y;
-    if (r >= r1) return;
-    zero_planes_row(lay, vcol0 + blockIdx.z, r, c0, P);
+    zero_planes_rows(lay, vcol0 + blockIdx.z, r0, r1, c0, 0xFFFFFFFFu, P);
 }
 
-__global__ __launch_bounds__(128) void k_zero_planes_cursor(LayoutDev lay, const uint64_t *__restrict__ d_cursor, uint8_t *__restrict__ P)
+__global__ __launch_bounds__(256) void k_zero_planes_cursor(LayoutDev lay, const uint64_t *__restrict__ d_cursor, uint8_t *__restrict__ P)
 {
     const uint64_t v_end = *d_cursor;
     uint64_t vcol = v_end / lay.Vc;
     const uint64_t c0 = v_end - vcol * lay.Vc;
     if (c0 == 0) return;                       // the cursor sits on a column boundary: nothing is open
     if (lay.ring) vcol %= lay.ring;
-    const uint32_t r = blockIdx.y;             // padded sample row
-    zero_planes_row(lay, vcol, r, r < lay.S ? c0 : 0ull, P);
+    zero_planes_rows(lay, vcol, 0u, lay.n_sc * lay.Sc, c0, lay.S, P);
 }
 
 int launch_pad_tail_planes_cursor(LayoutDev lay, const uint64_t *d_cursor, uint8_t *d_P, hipStream_t st)
 {
     const uint32_t S_pad = lay.n_sc * lay.Sc;
     if (S_pad == 0) return HHGT_OK;
-    const uint64_t bpr = lay.Vc >> 12;
-    hipLaunchKernelGGL(k_zero_planes_cursor, dim3((uint32_t)(bpr < 64 ? bpr : 64), S_pad), dim3(128), 0, st, lay, d_cursor, d_P);
+    const uint32_t tpc = (uint32_t)(lay.Vc / PL_TILE);
+    hipLaunchKernelGGL(k_zero_planes_cursor, dim3(tpc < 32 ? tpc : 32, (S_pad + 31) / 32), dim3(256), 0, st, lay, d_cursor, d_P);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
@@ -787,17 +852,17 @@ int launch_pad_tail_planes_cursor(LayoutDev lay, const uint64_t *d_cursor, uint8
 int launch_pad_tail_planes(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, uint8_t *d_P, hipStream_t st)
 {
     const uint32_t S_pad = lay.n_sc * lay.Sc;
-    const uint64_t bpr = lay.Vc >> 12;
-    const uint32_t gx = (uint32_t)(bpr < 64 ? bpr : 64);
+    const uint32_t tpc = (uint32_t)(lay.Vc / PL_TILE);
+    const uint32_t gx = tpc < 32 ? tpc : 32;
     if (v_end % lay.Vc) {   // (a) variant padding of the last touched chunk column
         const uint64_t vcol = v_end / lay.Vc;
         if (vcol < vcol_end && vcol >= vcol_begin && S_pad)
-            hipLaunchKernelGGL(k_zero_planes_rect, dim3(gx, S_pad), dim3(128), 0, st, lay, vcol, 0u, S_pad, v_end - vcol * lay.Vc, d_P);
+            hipLaunchKernelGGL(k_zero_planes_rect, dim3(gx, (S_pad + 31) / 32), dim3(256), 0, st, lay, vcol, 0u, S_pad, v_end - vcol * lay.Vc, d_P);
     }
     if (S_pad > lay.S) {    // (b) sample padding rows of every touched chunk column
         for (uint64_t v0 = vcol_begin; v0 < vcol_end; v0 += 65535) {
             const uint32_t nz = (uint32_t)(vcol_end - v0 < 65535 ? vcol_end - v0 : 65535);
-            hipLaunchKernelGGL(k_zero_planes_rect, dim3(gx, S_pad - lay.S, nz), dim3(128), 0, st, lay, v0, lay.S, S_pad, 0ull, d_P);
+            hipLaunchKernelGGL(k_zero_planes_rect, dim3(gx, (S_pad - lay.S + 31) / 32, nz), dim3(256), 0, st, lay, v0, lay.S, S_pad, 0ull, d_P);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -805,15 +870,24 @@ int launch_pad_tail_planes(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, u
 }
 
 // -------------------------------------------------------------------------------------------------
-// planes -> int8 bytes of the block (the inverse of the packing; for consumers that want the matrix after all and for
-// the parity tests).  One workgroup per Blosc block, thread t owns variants [16 t, 16 t + 16).
-__global__ __launch_bounds__(256) void k_planes_expand(const uint8_t *__restrict__ P, const uint8_t *G, uint8_t *out)   // out may be G
+// planes -> int8 bytes (the inverse of the packing; for consumers that want the matrix after all and for the parity
+// tests).  One workgroup per Blosc block (one sample row x 4096 variants = 16 tiles), thread t owns variants
+// [16 t, 16 t + 16): 2 bytes of each kind-plane piece of tile t / 16.
+__global__ __launch_bounds__(256) void k_planes_expand(LayoutDev lay, PlanesGeom pg, const uint8_t *__restrict__ P, const uint8_t *G,
+                                                       uint8_t *out, uint64_t id0)   // out may be G
 {
-    const uint64_t blk = blockIdx.x;
-    const uint16_t *pl = reinterpret_cast<const uint16_t *>(P + blk * 2048ull);
+    uint64_t col;
+    uint32_t row, bi;
+    planes_block(pg, id0 + blockIdx.x, &col, &row, &bi);
     const uint32_t t = threadIdx.x;
-    const uint32_t o0 = pl[t], o1 = pl[256 + t], e0 = pl[512 + t], e1 = pl[768 + t];
-    const uint64_t base = blk * 8192ull + 32ull * t;
+    const uint32_t tile = bi * 16u + (t >> 4), sub = t & 15u;   // 16-bit word `sub` of the tile's 32-byte piece
+    const uint64_t kstride = (uint64_t)pg.S_pad * 16ull;        // 16-bit words between kind-planes
+    const uint16_t *pl = reinterpret_cast<const uint16_t *>(P + planes_piece(pg, col, tile, 0u, row)) + sub;
+    const uint32_t o0 = pl[0], o1 = pl[kstride], e0 = pl[2ull * kstride], e1 = pl[3ull * kstride];
+    // byte offset of the block inside the int8 matrix (chunk-tiled layout: column, sample chunk, row in chunk)
+    const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (row >> lay.sc_log2);
+    const uint32_t sin = row - scol * lay.Sc;
+    const uint64_t base = ((((col * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc) + (uint64_t)bi * 4096ull + 16ull * t) * 2ull;
     uint32_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -833,17 +907,17 @@ __global__ __launch_bounds__(256) void k_planes_expand(const uint8_t *__restrict
     dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-int launch_planes_expand(const uint8_t *d_P, const uint8_t *d_G, uint64_t n_blocks, uint8_t *d_out, hipStream_t st)
+int launch_planes_expand(LayoutDev lay, const uint8_t *d_P, const uint8_t *d_G, uint32_t col0, uint32_t n_cols, uint8_t *d_out, hipStream_t st)
 {
+    const PlanesGeom pg = planes_geom(lay, col0);
+    const uint64_t n_blocks = (uint64_t)n_cols * pg.S_pad * pg.bpr;
     for (uint64_t b0 = 0; b0 < n_blocks; b0 += 0x40000000ull) {
         const uint64_t nb = n_blocks - b0 < 0x40000000ull ? n_blocks - b0 : 0x40000000ull;
-        hipLaunchKernelGGL(k_planes_expand, dim3((uint32_t)nb), dim3(256), 0, st, d_P + b0 * 2048ull, d_G ? d_G + b0 * 8192ull : nullptr,
-                           d_out + b0 * 8192ull);
+        hipLaunchKernelGGL(k_planes_expand, dim3((uint32_t)nb), dim3(256), 0, st, lay, pg, d_P, d_G, d_out, b0);
     }
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
-
 int launch_pad_tail(LayoutDev lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end, int8_t *d_G,
                     hipStream_t st)
 {

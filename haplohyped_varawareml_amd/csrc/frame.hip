@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
                                                      const unsigned long long *__restrict__ chunk_off,
                                                      const uint32_t *__restrict__ chunk_flags,
                                                      uint8_t *__restrict__ dst, uint64_t dst_cap,
-                                                     uint64_t n_total_blocks, const uint8_t *__restrict__ planes)
+                                                     uint64_t n_total_blocks, const uint8_t *__restrict__ planes, PlanesGeom pg)
 {
     // one wave per Blosc block (blocks are a few KiB after compression: a whole workgroup per block idles)
     const uint64_t gb = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -241,12 +241,16 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
         const uint8_t *s = src + chunk * P.chunk_nbytes + boff;
         uint8_t *d = cdst + P.hl + boff;
         if (planes) {   // the block exists as bit planes (hhgt.h "Bit-plane form"): its bytes are generated (rare: an incompressible chunk)
-            const uint8_t *pl = planes + gb * 2048ull;
+            uint64_t pcol;
+            uint32_t prow, pbi;
+            planes_block(pg, gb, &pcol, &prow, &pbi);
+            const uint64_t kst = (uint64_t)pg.S_pad * 32ull;   // bytes between the kind-planes of a tile
             for (uint32_t i = lane; i < 4096u; i += 64u) {
+                const uint8_t *pl = planes + planes_piece(pg, pcol, pbi * 16u + (i >> 8), 0u, prow) + ((i & 255u) >> 3);
 #pragma unroll
                 for (uint32_t h = 0; h < 2u; ++h) {
-                    uint32_t v = (pl[512u * h + (i >> 3)] >> (i & 7u)) & 1u;
-                    if ((pl[1024u + 512u * h + (i >> 3)] >> (i & 7u)) & 1u) v = v ? 0xF7u : (src ? (uint32_t)s[2u * i + h] : 0u);
+                    uint32_t v = (pl[h * kst] >> (i & 7u)) & 1u;
+                    if ((pl[(2ull + h) * kst] >> (i & 7u)) & 1u) v = v ? 0xF7u : (src ? (uint32_t)s[2u * i + h] : 0u);
                     d[2u * i + h] = (uint8_t)v;
                 }
             }
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
 }
 
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
-                 uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
+                 PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
                  uint32_t *d_bstart, uint64_t *d_chunk_csize, uint8_t *d_dst, uint64_t dst_cap,
                  uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st)
 {
@@ -308,7 +312,7 @@ int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_
     const uint64_t n_total_blocks = n_chunks * P.nblocks;
     hipLaunchKernelGGL(k_frame_write, dim3((uint32_t)((n_total_blocks + 3) / 4)), dim3(256), 0, st, P, d_scratch,
                        d_csize, d_src, d_bstart, reinterpret_cast<const unsigned long long *>(d_chunk_off),
-                       d_chunk_flags, d_dst, dst_cap, n_total_blocks, d_planes);
+                       d_chunk_flags, d_dst, dst_cap, n_total_blocks, d_planes, pg);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

@@ -650,7 +650,8 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
                                                      uint32_t *__restrict__ csize, const uint32_t *__restrict__ marked,
-                                                     const uint32_t *__restrict__ n_marked, const uint8_t *__restrict__ planes)
+                                                     const uint32_t *__restrict__ n_marked, const uint8_t *__restrict__ planes,
+                                                     PlanesGeom pg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
@@ -682,9 +683,13 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     if (planes) {
         // the block exists as bit planes (include/hhgt.h "Bit-plane form"; typesize 2, 8 KiB blocks): the shuffled byte
         // planes are generated from the bits; bytes of calls beyond 0 / 1 / missing come from their place in src
-        const uint8_t *pl = planes + (uint64_t)bid * 2048u;
+        uint64_t pcol;
+        uint32_t prow, pbi;
+        planes_block(pg, bid, &pcol, &prow, &pbi);
+        const uint64_t kst = (uint64_t)pg.S_pad * 32ull;   // bytes between the kind-planes of a tile
         for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) {   // byte i of each plane = variants 8 i .. 8 i + 7
-            const uint32_t o[2] = {pl[i], pl[512u + i]}, e[2] = {pl[1024u + i], pl[1536u + i]};
+            const uint8_t *pl = planes + planes_piece(pg, pcol, pbi * 16u + (i >> 5), 0u, prow) + (i & 31u);
+            const uint32_t o[2] = {pl[0], pl[kst]}, e[2] = {pl[2ull * kst], pl[3ull * kst]};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint32_t w[2] = {0u, 0u};
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     }
 }
 
-int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
                       int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
                       uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st)
 {
@@ -772,7 +777,7 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, uint64_t n_
         // effort: candidates tried per one along the hash chain (clevel 1-2: none, offset-1 runs only)
         static const int depth_env = getenv("HHGT_LZ4_DEPTH") ? atoi(getenv("HHGT_LZ4_DEPTH")) : -1;
         const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 16);
-        const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, n_chunks * (chunk_nbytes / 8192), d_scratch,
+        const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, pg, n_chunks * (chunk_nbytes / 8192), d_scratch,
                                             slot_bytes, d_csize, d_marked, d_n_marked, depth, st);
         if (rc != HHGT_OK) return rc;
     }
@@ -845,7 +850,7 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, uint64_t n_
 #define LZ_LAUNCH(MWV, ALG)                                                                                          \
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
-                       (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked, d_planes)
+                       (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked, d_planes, pg)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)
     if ((algo & 0xFFu) == 1u) LZ_LAUNCH(0, 1);

@@ -185,13 +185,18 @@ __device__ __forceinline__ void bp_flush(const uint8_t *stage, uint8_t *__restri
 // grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
 // DEPTH = candidates tried per one along the hash chain (1: the table's entry only; 0: no hash matches at all,
 // offset-1 runs only — the fastest level)
-// PLANES: src is the bit-plane form of the matrix (include/hhgt.h; 2048 bytes per block, written by k_encode_planes):
-// the wave's bit map is 512 bytes it loads as they are, and a set EXC bit is what "a byte > 1" was.
+// PLANES: src is the bit-plane form of the matrix (include/hhgt.h, tile-major: common.h; written by k_encode_planes): the
+// wave's bit map is 16 pieces of 32 bytes it gathers as they are (one load instruction: lane l takes 8 bytes of tile
+// l / 4), and a set EXC bit is what "a byte > 1" was.  The pieces of four neighbouring sample rows share a 128-byte
+// line, so the blocks are dealt to the workgroups in an XCD-aware order: of 64 consecutive workgroups the eight that land
+// on one XCD (round robin) take eight consecutive blocks — one L2 fetches each line once.
 template <int DEPTH, bool PLANES>
-__global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, uint8_t *__restrict__ scratch,
-                                                          uint64_t slot_bytes, uint32_t *__restrict__ csize,
+__global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
+                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
                                                           uint32_t *__restrict__ marked, uint32_t *__restrict__ n_marked)
 {
+    const uint32_t bid = PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
+    if (PLANES && bid >= n_blocks) return;   // (the grid is rounded up to whole groups of 64)
     constexpr bool CHAIN = DEPTH > 1;
     __shared__ BpLds<CHAIN> lds[2];
     __shared__ uint32_t nonbin[2][2];
@@ -201,8 +206,11 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     bool nonbinary;
     if (PLANES) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 *pl = reinterpret_cast<const u32x2 *>(src + (uint64_t)blockIdx.x * 2048u + 512u * wave) + lane;
-        const u32x2 one = __builtin_nontemporal_load(pl), exc = __builtin_nontemporal_load(pl + 128);   // streamed once
+        uint64_t col;
+        uint32_t row, bi;
+        planes_block(pg, bid, &col, &row, &bi);
+        const u32x2 *pl = reinterpret_cast<const u32x2 *>(src + planes_piece(pg, col, bi * 16u + (lane >> 2), wave, row)) + (lane & 3u);
+        const u32x2 one = *pl, exc = *(pl + (uint64_t)pg.S_pad * 8ull);   // EXC: two kind-planes (S_pad * 32 bytes each) further
         wlo = one.x;
         whi = one.y;
         lds[wave].bm[2u * lane] = wlo;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         if (threadIdx.x == 0) queued = 0u;
         __syncthreads();   // (for `queued` only: each wave works on what it loaded itself)
     } else {
-    const uint8_t *blk = src + (uint64_t)blockIdx.x * 8192u;
+    const uint8_t *blk = src + (uint64_t)bid * 8192u;
 
     // ---- phase A: wave r packs the bits of block bytes [4096 r, 4096 r + 4096) for BOTH planes (byte-shuffle fused:
     //      even bytes are plane 0, odd bytes plane 1).  Load k of a lane is the 16 bytes at 1024 k + 16 lane: every load
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
 #endif
     uint32_t sink = 0;
     if (BP_SKIP >= 5) {
-        if (lane == 0) csize[(uint64_t)blockIdx.x * 2u + wave] = lds[wave].bm[5] & 1u;
+        if (lane == 0) csize[(uint64_t)bid * 2u + wave] = lds[wave].bm[5] & 1u;
         return;
     }
 
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     uint16_t *P = S.P;
     uint16_t *wpre = S.wpre;
     uint32_t *flag = S.flag;
-    const uint64_t sidx = (uint64_t)blockIdx.x * 2u + wave;
+    const uint64_t sidx = (uint64_t)bid * 2u + wave;
     uint8_t *out = scratch + sidx * slot_bytes;
 
     const uint32_t cnt = (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     if (nonbinary || m > BP_MAXONES) {
         if (lane == 0) {   // left to the byte-wise encoder: mark the stream, queue its block (once: two workgroups on one
             csize[sidx] = 0xFFFFFFFFu;   // block would write two different valid encodings into the same slot)
-            if (atomicExch(&queued, 1u) == 0u) marked[atomicAdd(n_marked, 1u)] = blockIdx.x;
+            if (atomicExch(&queued, 1u) == 0u) marked[atomicAdd(n_marked, 1u)] = bid;
         }
         return;
     }
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     if (lane == 0) csize[sidx] = op;
 }
 
-int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
+int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
                          uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st)
 {
     if (n_blocks == 0) return HHGT_OK;
@@ -607,8 +615,8 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, uint64_t n_blocks, u
     // wave slots to a kernel running beside this one on another stream
     static const int lds_pad = getenv("HHGT_LZ4_LDS_PAD") ? atoi(getenv("HHGT_LZ4_LDS_PAD")) : 0;
 #define BP_LAUNCH2(D, PL)                                                                                                   \
-    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL>), dim3((uint32_t)n_blocks), dim3(128), lds_pad, st, d_src, d_scratch, (uint64_t)slot_bytes, \
-                       d_csize, d_marked, d_n_marked)
+    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
+                       d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked)
 #define BP_LAUNCH(D)            \
     do {                        \
         if (planes) BP_LAUNCH2(D, true); \

@@ -228,14 +228,16 @@ class Context:
         with torch.cuda.device(self.device):
             check(self.lib.hhgt_pad_tail_planes(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end), _ptr(res.P), _stream()))
 
-    def compress_planes(self, P, G, chunk_nbytes, fmt=BLOSC2, dst=None, chunk_off=None, sync=True):
-        """hhgt_compress_planes: P holds the planes of n_chunks chunks of chunk_nbytes int8 bytes each (typesize 2,
-        8 KiB blocks); G (or None) the int8 matrix whose bytes back the calls beyond 0 / 1 / missing.
+    def compress_planes(self, res, col0=0, n_cols=None, fmt=BLOSC2, dst=None, chunk_off=None, sync=True):
+        """hhgt_compress_planes: the chunks of column slots [col0, col0 + n_cols) of res (res.P: the planes; res.G or None:
+        the int8 matrix whose bytes back the calls beyond 0 / 1 / missing), typesize 2, 8 KiB blocks.
         -> (dst, chunk_off, total_bytes or None) like compress()"""
-        assert P.is_cuda and P.dtype == torch.uint8 and P.is_contiguous()
-        chunk_nbytes = int(chunk_nbytes)
-        assert chunk_nbytes % 8192 == 0 and (P.numel() * 4) % chunk_nbytes == 0
-        n_chunks = P.numel() * 4 // chunk_nbytes
+        lay = res.layout
+        Vc, Sc = lay.vc or lay.v_capacity, lay.sc or max(lay.n_samples, 1)
+        if n_cols is None:
+            n_cols = lay.v_capacity // Vc - col0
+        n_chunks = n_cols * (-(-lay.n_samples // Sc) if lay.sc else 1)
+        chunk_nbytes = Sc * Vc * 2
         with torch.cuda.device(self.device):
             cap = int(self.lib.hhgt_compress_bound(n_chunks, chunk_nbytes, 2, 8192))
             if dst is None:
@@ -243,39 +245,22 @@ class Context:
             if chunk_off is None:
                 chunk_off = torch.zeros(n_chunks + 1, dtype=torch.int64, device=self.device)
             total = C.c_uint64(0)
-            check(self.lib.hhgt_compress_planes(self.h, _ptr(P), _ptr(G), n_chunks, chunk_nbytes, fmt, _ptr(dst), dst.numel(),
-                                                _ptr(chunk_off), C.byref(total) if sync else None, _stream()))
+            check(self.lib.hhgt_compress_planes(self.h, C.byref(lay), _ptr(res.P), _ptr(res.G), int(col0), int(n_cols), fmt, _ptr(dst),
+                                                dst.numel(), _ptr(chunk_off), C.byref(total) if sync else None, _stream()))
         return dst, chunk_off, (int(total.value) if sync else None)
 
-    def planes_expand(self, P, G=None, out=None):
-        """hhgt_planes_expand: planes (+ G's bytes for the calls beyond 0 / 1 / missing) -> the int8 matrix bytes"""
-        assert P.is_cuda and P.dtype == torch.uint8 and P.numel() % 2048 == 0
-        n_blocks = P.numel() // 2048
-        with torch.cuda.device(self.device):
-            if out is None:
-                out = torch.empty(n_blocks * 8192, dtype=torch.uint8, device=self.device)
-            check(self.lib.hhgt_planes_expand(self.h, _ptr(P), _ptr(G), n_blocks, _ptr(out), _stream()))
-        return out
-
-    def chrom_runs(self):
-        n = C.c_uint32(0)
-        check(self.lib.hhgt_encode_chrom_runs(self.h, 0, None, None, C.byref(n)))
-        if n.value == 0:
-            return []
-        first = np.zeros(n.value, np.uint64)
-        names = np.zeros((n.value, 32), np.uint8)
-        check(self.lib.hhgt_encode_chrom_runs(self.h, n.value, first.ctypes.data, names.ctypes.data, C.byref(n)))
-        return [(int(first[i]), bytes(names[i]).rstrip(b"\0").decode()) for i in range(n.value)]
-
-    def pad_tail(self, res, v_end=None, vcol_begin=0, vcol_end=None):
+    def planes_expand(self, res, col0=0, n_cols=None, out=None):
+        """hhgt_planes_expand: planes (+ res.G's bytes for the calls beyond 0 / 1 / missing) of column slots [col0, col0 + n_cols)
+        -> the int8 matrix bytes at their place in `out` (a buffer of the int8 layout; default: a new zeroed one)"""
         lay = res.layout
         Vc = lay.vc or lay.v_capacity
-        v_end = res.n_kept if v_end is None else v_end
-        if vcol_end is None:
-            vcol_end = -(-max(v_end, 1) // Vc)
+        if n_cols is None:
+            n_cols = lay.v_capacity // Vc - col0
         with torch.cuda.device(self.device):
-            check(self.lib.hhgt_pad_tail(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end),
-                                         _ptr(res.G), _stream()))
+            if out is None:
+                out = torch.zeros(layout_bytes(lay), dtype=torch.uint8, device=self.device)
+            check(self.lib.hhgt_planes_expand(self.h, C.byref(lay), _ptr(res.P), _ptr(res.G), int(col0), int(n_cols), _ptr(out), _stream()))
+        return out
 
     def create_stream(self, kind):
         """kind "encode" | "compress": the stream pair for running compress of one block beside encode of the next

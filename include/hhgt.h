@@ -211,22 +211,26 @@ int hhgt_decompress_chunks(hhgt_ctx *ctx, const void *d_src, const uint64_t *d_c
  * variant between the two halves shrink to S/2: the encoder writes, and the LZ4 coder reads, two BITS per allele.
  *
  * Geometry: typesize 2, Blosc blocks of 8192 bytes (= one sample x 4096 variants x 2 haplotypes), so the layout needs
- * vc % 4096 == 0 (dense: v_capacity % 4096 == 0).  Block b of G (bytes [8192 b, 8192 b + 8192) of the chunk-tiled
- * matrix, any layout incl. rings) has its planes at d_P + 2048 b:
- *     [   0,  512)  ONE bits, haplotype 0      bit i (little-endian dwords, LSB first) = variant i of the block
- *     [ 512, 1024)  ONE bits, haplotype 1
- *     [1024, 1536)  EXC bits, haplotype 0
- *     [1536, 2048)  EXC bits, haplotype 1
+ * vc % 4096 == 0 (dense: v_capacity % 4096 == 0).  The planes are TILE-MAJOR: a chunk column (vc variants x S_pad =
+ * round_up(S, sc) sample rows; rings: a column slot) is cut into tiles of 256 variants, and tile t of column slot c keeps,
+ * for each of four kind-planes kp and each sample row r, one 32-byte piece at
+ *     d_P + ((((c * (vc / 256) + t) * 4 + kp) * S_pad + r) * 32        bit i (little-endian dwords, LSB first) = variant
+ *                                                                        256 t + i of the column
+ *     kp 0: ONE bits, haplotype 0    kp 1: ONE bits, haplotype 1    kp 2: EXC bits, haplotype 0    kp 3: EXC bits, haplotype 1
+ * (so an encoder workgroup writes contiguous 8 KiB runs, and a compressor wave gathers the 16 pieces of its plane).
  * (ONE, EXC) = (0,0): allele 0; (1,0): allele 1; (1,1): missing, -9 (cpp/vcfpp.h:567-573); (0,1): any other value
- * (allele index >= 2, cpp/vcfpp.h:574) — its int8 byte sits at the call's ordinary position in d_G, which is written
- * there and nowhere else.  hhgt_encode_result.reserved counts those calls (saturating); d_G may be NULL where the
- * caller knows there are none (biallelic input under the reference's filter has none).
+ * (allele index >= 2, cpp/vcfpp.h:574) — its int8 byte sits at the call's ordinary position in d_G (same layout), which
+ * is written there and nowhere else.  hhgt_encode_result.reserved counts those calls (saturating); d_G may be NULL where
+ * the caller knows there are none (biallelic input under the reference's filter has none).
+ * hhgt_planes_bytes(lay) = hhgt_layout_bytes(lay) / 4.
  *
  * hhgt_encode_text_planes_async / hhgt_pad_tail_planes_cursor / hhgt_pad_tail_planes: as their int8 namesakes.
- * hhgt_compress_planes: as hhgt_compress_chunks with typesize 2, blocksize 8192 on the matrix the planes stand for
- *   (chunk_nbytes = int8 bytes of a chunk, a multiple of 8192; d_P holds n_chunks * chunk_nbytes / 4 bytes).
- * hhgt_planes_expand: planes (+ d_G's bytes for the (0,1) calls) -> int8 bytes, n_blocks blocks of 8192 bytes into
- *   d_out (d_out == d_G is allowed).  For consumers that want the matrix after all, and for the parity tests.
+ * hhgt_compress_planes: hhgt_compress_chunks (typesize 2, blocksize 8192) on the chunks of column slots
+ *   [col0, col0 + n_cols) of the matrix the planes stand for: n_cols * ceil(S / sc) chunks of sc * vc * 2 bytes, in the
+ *   int8 matrix's chunk order; d_P and d_G are the bases of the whole buffers.
+ * hhgt_planes_expand: planes (+ d_G's bytes for the (0,1) calls) of those column slots -> int8 bytes at their place in
+ *   d_out, a buffer of the int8 layout (d_out == d_G is allowed).  For consumers that want the matrix after all, and for
+ *   the parity tests.
  * ------------------------------------------------------------------------------------------- */
 uint64_t hhgt_planes_bytes(const hhgt_layout *lay);   /* 0 if the layout cannot carry planes */
 int hhgt_encode_text_planes_async(hhgt_ctx *ctx, const void *d_text, uint64_t nbytes, const char *region,
@@ -236,10 +240,11 @@ int hhgt_encode_text_planes_async(hhgt_ctx *ctx, const void *d_text, uint64_t nb
 int hhgt_pad_tail_planes_cursor(hhgt_ctx *ctx, const hhgt_layout *lay, const uint64_t *d_cursor, void *d_P, void *stream);
 int hhgt_pad_tail_planes(hhgt_ctx *ctx, const hhgt_layout *lay, uint64_t v_end, uint64_t vcol_begin, uint64_t vcol_end,
                          void *d_P, void *stream);
-int hhgt_compress_planes(hhgt_ctx *ctx, const void *d_P, const void *d_G, uint64_t n_chunks, uint64_t chunk_nbytes,
+int hhgt_compress_planes(hhgt_ctx *ctx, const hhgt_layout *lay, const void *d_P, const void *d_G, uint32_t col0, uint32_t n_cols,
                          int format, void *d_dst, uint64_t dst_cap, uint64_t *d_chunk_off, uint64_t *total_bytes,
                          void *stream);
-int hhgt_planes_expand(hhgt_ctx *ctx, const void *d_P, const void *d_G, uint64_t n_blocks, void *d_out, void *stream);
+int hhgt_planes_expand(hhgt_ctx *ctx, const hhgt_layout *lay, const void *d_P, const void *d_G, uint32_t col0, uint32_t n_cols,
+                       void *d_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Consumer side (BASELINE config 5): one-hot haplotype windows straight into a device tensor.

@@ -13,6 +13,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _legs_lines():
+    from tests import extlibs
+    from tests.test_h5file import h5_used
+    used = dict(extlibs.used, **h5_used)
+    return [f"independent decoder {name}: {'present' if ok else 'ABSENT'} ({what}); calls in this session: {used.get(name, 0)}"
+            for name, (ok, what) in extlibs.legs().items()]
+
+
+def pytest_report_header(config):
+    """which independent decoders (base-image libraries, not reference code) the parity tests can lean on here"""
+    return [ln.split(";")[0] for ln in _legs_lines()]
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """... and how often each was really called: the oracle's own decoder always runs, these legs only where loadable"""
+    terminalreporter.section("independent decoders", sep="-")
+    for ln in _legs_lines():
+        terminalreporter.write_line(ln)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -35,6 +35,11 @@ if _blosc is not None:
     _blosc.blosc_decompress_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
 
+# how often each independent leg actually ran in this session (tests/conftest.py prints it in the terminal summary, so a
+# run's log says which legs the parity tests really had — a leg that is absent is otherwise a silent `if`)
+used = {"liblz4": 0, "c-blosc": 0}
+
+
 def have_lz4():
     return _lz4 is not None
 
@@ -43,9 +48,18 @@ def have_blosc():
     return _blosc is not None
 
 
+def legs():
+    """-> {name: (present, what it is)} of the independent decoders the tests use when they can be loaded"""
+    from tests.test_h5file import have_h5py
+    return {"liblz4": (have_lz4(), "system liblz4 (LZ4_decompress_safe on every LZ4 stream)"),
+            "c-blosc": (have_blosc(), "c-blosc 1.x (blosc_decompress_ctx on Blosc-1 chunks; shuffle + header + bstarts)"),
+            "libhdf5": (have_h5py(), "h5py / libhdf5 under /opt/conda (the .h5 container, read_direct_chunk, filter pipeline)")}
+
+
 def lz4_decompress(comp, nbytes):
     comp = np.ascontiguousarray(comp, dtype=np.uint8)
     out = np.empty(max(nbytes, 1), np.uint8)
+    used["liblz4"] += 1
     n = _lz4.LZ4_decompress_safe(comp.ctypes.data, out.ctypes.data, comp.size, nbytes)
     if n < 0:
         raise RuntimeError(f"LZ4_decompress_safe rc={n}")
@@ -64,6 +78,7 @@ def lz4_compress(buf):
 def blosc1_decompress(chunk, nbytes):
     chunk = np.ascontiguousarray(chunk, dtype=np.uint8)
     out = np.empty(max(nbytes, 1), np.uint8)
+    used["c-blosc"] += 1
     n = _blosc.blosc_decompress_ctx(chunk.ctypes.data, out.ctypes.data, nbytes, 1)
     if n < 0:
         raise RuntimeError(f"blosc_decompress_ctx rc={n}")

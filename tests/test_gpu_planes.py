@@ -66,7 +66,7 @@ def test_fixed_width_planes_vs_oracle(ctx, S, V, sc, vc, nblk):
     lay = dev.make_layout(S, cap, sc=sc, vc=vc) if vc else dev.Layout(S, 0, 0, 0, cap)
     res, n, recs = _encode_planes(ctx, text, S, lay, "chr5", nblk, with_g=False)
     assert n == V == o["n_kept"] and all(r.reserved == 0 for r in recs)
-    back = ctx.planes_expand(res.P)
+    back = ctx.planes_expand(res)
     assert np.array_equal(_dense_from_bytes(back, lay, V), o["G"])
     # nothing but zeros behind the last variant and in the sample padding rows
     full = dev.EncodeResult(back, lay, None, None, None, None, lay.v_capacity, {}).dense()
@@ -96,7 +96,7 @@ def test_mixed_c4_planes_vs_oracle(ctx):
     assert nk == o["n_kept"] and sum(r.stats.n_drop_filter for r in recs) == o["stats"]["n_drop_filter"]
     assert all(r.reserved == 0 for r in recs)                 # under the reference's filter: 0, 1 and missing only
     assert sum(r.stats.n_general_lines for r in recs) == int(t["with_dp"][np.nonzero(t["kept"])[0]].sum())
-    back = ctx.planes_expand(res.P)
+    back = ctx.planes_expand(res)
     G = _dense_from_bytes(back, lay, nk)
     assert (o["G"] == -9).any()
     assert np.array_equal(G, o["G"])
@@ -109,7 +109,7 @@ def test_fixture_planes_vs_golden(ctx, fixture_text, golden_dir):
     lay = dev.make_layout(3, 4096, sc=64, vc=4096)
     res, n, recs = _encode_planes(ctx, fixture_text, 3, lay, "chr22", 2, max_lines=lambda t_: t_.numel() // 16 + 8)
     assert n == 1000
-    G = _dense_from_bytes(ctx.planes_expand(res.P, res.G), lay, n)
+    G = _dense_from_bytes(ctx.planes_expand(res), lay, n)
     assert np.array_equal(G, want)
 
 
@@ -130,12 +130,12 @@ def test_keep_multiallelic_other_calls(ctx):
     assert nk == o["n_kept"]
     n_other = int(((o["G"] != 0) & (o["G"] != 1) & (o["G"] != -9)).sum())
     assert sum(r.reserved for r in recs) >= n_other > 0      # (a line re-done by the variable-width kernel counts again)
-    G = _dense_from_bytes(ctx.planes_expand(res.P, res.G), lay, nk)
+    G = _dense_from_bytes(ctx.planes_expand(res), lay, nk)
     assert np.array_equal(G, o["G"])
     # compressed from the planes (+ G for the other calls): every chunk decodes to the oracle's bytes
     want = np.zeros((-(-S // 64) * 64, lay.v_capacity, 2), np.int8)
     want[:S, :nk] = o["G"]
-    dst, off, total = ctx.compress_planes(res.P, res.G, 64 * 4096 * 2, fmt=dev.BLOSC1)
+    dst, off, total = ctx.compress_planes(res, fmt=dev.BLOSC1)
     chunks = split_chunks(dst, off, total)
     k = 0
     for vcol in range(lay.v_capacity // 4096):
@@ -163,7 +163,7 @@ def test_compress_planes_decodes_to_oracle_matrix(ctx, shape):
     assert n == nk
     chunk_nbytes = 64 * 8192 * 2
     for fmt in (dev.BLOSC1, dev.BLOSC2):
-        dst, off, total = ctx.compress_planes(res.P, None, chunk_nbytes, fmt=fmt)
+        dst, off, total = ctx.compress_planes(res, fmt=fmt)
         chunks = split_chunks(dst, off, total)
         want = np.zeros((-(-S // 64) * 64, lay.v_capacity, 2), np.int8)
         want[:S, :nk] = o["G"]
@@ -176,7 +176,7 @@ def test_compress_planes_decodes_to_oracle_matrix(ctx, shape):
         # the int8 path on the expanded matrix: same chunks, byte for byte (the bit-plane coder sees the same bit maps).
         # Only where every stream is the bit-plane coder's: the byte-wise kernel that codes planes with missing calls
         # emits valid streams whose bytes are not reproducible from run to run, from either input.
-        raw = ctx.planes_expand(res.P)
+        raw = ctx.planes_expand(res)
         if shape == "fixed":
             dst8, off8, total8 = ctx.compress(raw, chunk_nbytes, typesize=2, blocksize=8192, fmt=fmt)
             assert total8 == total and torch.equal(off8, off) and torch.equal(dst8[:total8], dst[:total])
@@ -195,14 +195,16 @@ def test_ring_of_plane_columns(ctx):
     ctx.pad_tail_planes(res, lay.v_capacity, 0, ring)          # sample padding rows of every ring column, once
     cursor = torch.zeros(1, dtype=torch.int64, device=ctx.device)
     n_sc = 2
-    colP = n_sc * 64 * vc // 2
+    col_bytes = n_sc * 64 * vc * 2
     ncol = -(-V // vc)
     got = np.zeros((n_sc * 64, ncol * vc, 2), np.int8)
     done = 0
+    scratch = torch.zeros(dev.layout_bytes(lay), dtype=torch.uint8, device=ctx.device)
 
     def take(col):
         slot = col % ring
-        raw = ctx.planes_expand(res.P[slot * colP:(slot + 1) * colP])
+        ctx.planes_expand(res, col0=slot, n_cols=1, out=scratch)
+        raw = scratch[slot * col_bytes:(slot + 1) * col_bytes]
         got[:, col * vc:(col + 1) * vc] = raw.view(torch.int8).view(n_sc, 64, vc, 2).reshape(n_sc * 64, vc, 2).cpu().numpy()
 
     for blk in _blocks(text, 23):                      # ~1300 variants per block: less than a column, odd phases
@@ -215,38 +217,53 @@ def test_ring_of_plane_columns(ctx):
     ctx.pad_tail_planes_cursor(res, cursor)
     take(done)
     assert np.array_equal(got[:S, :V], o["G"]) and not got[S:].any() and not got[:, V:].any()
+    # one ring slot compressed on its own: its two chunks decode to the column the slot holds now
+    slot = done % ring
+    dst, off, total = ctx.compress_planes(res, col0=slot, n_cols=1, fmt=dev.BLOSC1)
+    for scol, ck in enumerate(split_chunks(dst, off, total)):
+        back = oracle.blosc_decompress(ck).view(np.int8).reshape(64, vc, 2)
+        assert np.array_equal(back, got[scol * 64:(scol + 1) * 64, done * vc:(done + 1) * vc])
 
 
 def test_incompressible_planes_are_stored(ctx):
     """every call an 'other' call (EXC without ONE) whose byte in G is random: nothing compresses, Blosc stores the chunk
-    verbatim (memcpyed) and the framing generates the bytes from planes + G; the oracle decodes them to G's bytes"""
+    verbatim (memcpyed) and the framing generates the bytes from planes + G; the oracle decodes them to G's bytes.
+    The planes are written by hand here, which also pins the documented tile-major layout (include/hhgt.h)."""
     rng = np.random.default_rng(7)
-    n_blocks = 64
-    P = np.zeros((n_blocks, 4, 512), np.uint8)
-    P[:, 2:] = 0xFF
-    G = rng.integers(0, 256, n_blocks * 8192, dtype=np.uint8)
-    Pd, Gd = to_dev(P.reshape(-1)), to_dev(G)
-    raw = ctx.planes_expand(Pd, Gd)
-    assert np.array_equal(raw.cpu().numpy(), G)
-    # a sparse block in between still expands from its bits alone
+    S, vc, ncol = 16, 4096, 4
+    lay = dev.make_layout(S, ncol * vc, sc=16, vc=vc)
+    assert dev.planes_bytes(lay) == ncol * 16 * 4 * 16 * 32
+    P = np.zeros((ncol, vc // 256, 4, 16, 32), np.uint8)      # [column][tile][kind-plane][sample row][32 B]
+    P[:, :, 2:] = 0xFF
+    G = rng.integers(0, 256, dev.layout_bytes(lay), dtype=np.uint8)
+    res = dev.EncodeResult(to_dev(G), lay, None, None, None, None, 0, {}, [], to_dev(P.reshape(-1)))
+    assert np.array_equal(ctx.planes_expand(res).cpu().numpy(), G)
+    # a sparse (sample row, 4096-variant block) in between still expands from its bits alone: column 1, row 5
     P2 = P.copy()
-    P2[5] = 0
-    P2[5, 0, 17] = 0x81
-    P2[5, 1, 200] = 0x10
-    P2[5, 3, 200] = 0x10
-    raw2 = ctx.planes_expand(to_dev(P2.reshape(-1)), Gd).cpu().numpy().view(np.int8).reshape(n_blocks, 4096, 2)
-    want5 = np.zeros((4096, 2), np.int8)
-    want5[17 * 8, 0] = want5[17 * 8 + 7, 0] = 1
-    want5[200 * 8 + 4, 1] = -9
-    assert np.array_equal(raw2[5], want5) and np.array_equal(raw2[6].reshape(-1).view(np.uint8), G[6 * 8192:7 * 8192])
-    chunk_nbytes = 16 * 8192
+    P2[1, :, :, 5, :] = 0
+    P2[1, 0, 0, 5, 17] = 0x81            # haplotype 0: allele 1 at variants 136 and 143
+    P2[1, 6, 1, 5, 8] = 0x10             # haplotype 1: ONE ...
+    P2[1, 6, 3, 5, 8] = 0x10             # ... and EXC at variant 6 * 256 + 68: a missing call
+    res2 = dev.EncodeResult(res.G, lay, None, None, None, None, 0, {}, [], to_dev(P2.reshape(-1)))
+    raw2 = ctx.planes_expand(res2).cpu().numpy().view(np.int8).reshape(ncol, 16, vc, 2)      # [column][row][variant][h]
+    want5 = np.zeros((vc, 2), np.int8)
+    want5[136, 0] = want5[143, 0] = 1
+    want5[6 * 256 + 68, 1] = -9
+    assert np.array_equal(raw2[1, 5], want5)
+    assert np.array_equal(raw2[1, 6].reshape(-1).view(np.uint8), G.reshape(ncol, 16, vc * 2)[1, 6])
+    chunk_nbytes = 16 * vc * 2
     for fmt in (dev.BLOSC1, dev.BLOSC2):
-        dst, off, total = ctx.compress_planes(Pd, Gd, chunk_nbytes, fmt=fmt)
+        dst, off, total = ctx.compress_planes(res, fmt=fmt)
         chunks = split_chunks(dst, off, total)
-        assert len(chunks) == 4
+        assert len(chunks) == ncol
         for i, ch in enumerate(chunks):
             assert ch[2] & 0x2, "chunk should be stored verbatim"
             assert np.array_equal(oracle.blosc_decompress(ch), G[i * chunk_nbytes:(i + 1) * chunk_nbytes])
+    # the hand-made sparse block through the compressor as well (its chunk is compressible no more than the others:
+    # still stored; what matters is that it decodes to the expansion)
+    dst, off, total = ctx.compress_planes(res2, col0=1, n_cols=1, fmt=dev.BLOSC1)
+    ck = split_chunks(dst, off, total)[0]
+    assert np.array_equal(oracle.blosc_decompress(ck).view(np.int8).reshape(16, vc, 2), raw2[1])
 
 
 def test_bad_layout_is_refused(ctx):

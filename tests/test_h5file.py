@@ -1,6 +1,7 @@
 """CPU: the native HDF5 writer (haplohyped_varawareml_amd/h5file.py) against an independent reader — the image's
 libhdf5 1.10.6 through h5py 3.3 in /opt/conda (an interpreter this test only shells out to; when it is absent the
 library-backed checks skip and only the self-contained ones run)."""
+import functools
 import json
 import os
 import struct
@@ -15,6 +16,10 @@ CONDA_PY = "/opt/conda/bin/python3.9"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+h5_used = {"libhdf5": 0}   # runs of the independent HDF5 reader in this session (tests/conftest.py prints it)
+
+
+@functools.lru_cache(maxsize=None)
 def have_h5py():
     if not os.path.exists(CONDA_PY):
         return False
@@ -29,6 +34,7 @@ needs_h5py = pytest.mark.skipif(not have_h5py(), reason="no independent HDF5 lib
 
 def h5check(path, tmp_path, *dump):
     out = str(tmp_path / "check.npz")
+    h5_used["libhdf5"] += 1
     r = subprocess.run([CONDA_PY, os.path.join(HERE, "h5check.py"), path, out, *dump], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(out, allow_pickle=False)

@@ -12,9 +12,9 @@ text = ctx.synth_mixed("chr2", synth.mixed_table(2, V, S), S, seed=2)[0].cpu().n
 lay = dev.make_layout(S, 12000, sc=64, vc=8192)
 res, n, _ = _encode_planes(ctx, text, S, lay, "chr2", 2, with_g=False, max_lines=lambda t: t.numel() // 16 + 8)
 cn = 64 * 8192 * 2
-raw = ctx.planes_expand(res.P)
+raw = ctx.planes_expand(res)
 def run_p():
-    d, o, t = ctx.compress_planes(res.P, None, cn, fmt=dev.BLOSC1)
+    d, o, t = ctx.compress_planes(res, fmt=dev.BLOSC1)
     return split_chunks(d, o, t)
 def run_b():
     d, o, t = ctx.compress(raw, cn, typesize=2, blocksize=8192, fmt=dev.BLOSC1)
