@@ -36,8 +36,9 @@
 #define BP_N 4096
 #define BP_MAXONES 636
 #ifndef BP_STAGE
-#define BP_STAGE 1024   // 512 would let 16 workgroups share a CU (LZ4 stage -5 %) but leaves no wave slots to the index kernel of the next shard running beside it: the step gets slower (28.8 against 27.2 ms)
+#define BP_STAGE 576    // staging area; with the queue below the workgroup stays under 11 KiB of LDS = 14 workgroups per CU
 #endif
+#define BP_QCAP 100     // queued coded ones a wave can hold (a window adds at most 64 to fewer than 64)
 #define BP_HLOG 6
 #define BP_GAPCLIP 40
 #define BP_MINM 6
@@ -55,13 +56,22 @@
 template <bool CHAIN> struct BpLds {
     uint32_t bm[132];                // bit map of the plane: 128 dwords + zero padding
     uint32_t tab[1 << BP_HLOG];      // min(gap behind the one + 1, BP_GAPCLIP) -> one index + 1
-    uint32_t flag[68];               // pointer-doubling marks of a window
+    uint8_t flag[72];                // pointer-doubling marks of a window
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
     uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
     uint16_t chain[CHAIN ? BP_MAXONES + 8 : 4];   // chain[j + 1] = (previous one with the same context hash) + 1, 0 = none
     uint32_t gbw[(BP_MAXONES + 16) / 4];   // gap bytes: zeros behind the one with P-index i, clipped to 255 (255 from the last one on)
+    uint2 queue[BP_QCAP];            // coded ones waiting for layout + emission (bp_emit_batch takes 64 at a time)
     uint8_t stage[BP_STAGE];         // output staged here, written out in coalesced dwords
 };
+
+// a queued coded one: what its sequences need that does not depend on the sequences in front of it
+//   x: E (13 bits) | msr = q - nb (13) << 13 | onM << 26 | onT << 27 | (rs - E) << 28        (E: end of what the one codes)
+//   y: re (13 bits) | off << 13                                                                (re: start of the next coded one)
+__device__ __forceinline__ uint2 bp_entry(uint32_t E, uint32_t msr, bool onM, bool onT, uint32_t rs, uint32_t re, uint32_t off)
+{
+    return make_uint2(E | ((msr & 0x1FFFu) << 13) | (onM ? 1u << 26 : 0u) | (onT ? 1u << 27 : 0u) | ((rs - E) << 28), re | (off << 13));
+}
 
 // wave-wide inclusive scans on DPP row shifts (no LDS round trips): sum and max of non-negative values
 __device__ __forceinline__ uint32_t bp_row_shr(uint32_t x, int d)
@@ -182,6 +192,55 @@ __device__ __forceinline__ void bp_flush(const uint8_t *stage, uint8_t *__restri
     if (t < n) dst[t] = stage[t];
 }
 
+#define BP_FENCE() asm volatile("" ::: "memory")
+// layout + emission of the first n (<= 64) queued coded ones, one per lane, in stream order.  The end of a coded one's
+// last sequence is where the next one's literals start (pe): the neighbouring lane's value, no scan.
+struct BpOut {
+    uint32_t prev_end, gop, sop;   // end of the last sequence; bytes written to global / staged
+};   // (by value: a reference across the "memory" fences would pin the counters to scratch memory)
+
+template <typename LDS>
+__device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8_t *__restrict__ out, uint32_t n, BpOut st, uint32_t lane)
+{
+    uint32_t prev_end = st.prev_end, gop = st.gop, sop = st.sop;
+    const bool have = lane < n;
+    const uint2 en = have ? S.queue[lane] : make_uint2(0u, 0u);
+    const uint32_t E = en.x & 0x1FFFu, msr = (en.x >> 13) & 0x1FFFu, rs = E + (en.x >> 28), re = en.y & 0x1FFFu, off = en.y >> 13;
+    const bool onM = (en.x >> 26) & 1u, onT = (en.x >> 27) & 1u;
+    const uint32_t F = onT ? re : E;                                   // end of this one's last sequence
+    uint32_t pe = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)F, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    pe = lane ? pe : prev_end;
+    uint32_t ms = msr > pe ? msr : pe;                                 // the previous sequence may have taken some of the zeros in front
+    ms = onM ? ms : 0u;
+    const uint32_t llM = onM ? ms - pe : 0u, lenM = E - ms;
+    const uint32_t pe2 = onM ? E : pe;
+    const uint32_t llT = onT ? rs - pe2 : 0u, lenT = re - rs;
+    const uint32_t szM = onM ? 3u + bp_len_ext(llM) + llM + bp_len_ext(lenM - 4u) : 0u;
+    const uint32_t szT = onT ? 3u + bp_len_ext(llT) + llT + bp_len_ext(lenT - 4u) : 0u;
+    const uint32_t sincl = bp_scan_sum(szM + szT, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+    BP_MARK("sizes_done");
+    // the batch's bytes go to the staging area; what is staged leaves in coalesced dwords when the next batch would not
+    // fit (a batch larger than the whole area is written to global memory directly)
+    if (sop + total > BP_STAGE) {
+        bp_flush(S.stage, out + gop, sop, lane);
+        gop += sop;
+        sop = 0;
+    }
+    const uint32_t at = sincl - (szM + szT);
+    if (total > BP_STAGE) {   // (wave-uniform, rare: a batch with hundreds of literals)
+        bp_put_seq(bm, out + gop, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq(bm, out + gop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+        gop += total;
+    } else {
+        bp_put_seq(bm, S.stage + sop, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq(bm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+        sop += total;
+    }
+    prev_end = (uint32_t)__builtin_amdgcn_readlane((int)F, (int)(n - 1u));
+    return BpOut{prev_end, gop, sop};
+}
+
 // grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
 // DEPTH = candidates tried per one along the hash chain (1: the table's entry only; 0: no hash matches at all,
 // offset-1 runs only — the fastest level)
@@ -283,12 +342,11 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     // hand-over below is an access whose address it cannot tell apart from the lane's own writes, and BP_FENCE marks
     // the phase boundaries for good measure.  (volatile pointers would also do — and turn every access into a
     // serialised flat load with its own wait, which made this kernel 2x slower than it had to be.)
-#define BP_FENCE() asm volatile("" ::: "memory")
     BpLds<CHAIN> &S = lds[wave];
     uint32_t *bm = S.bm;
     uint16_t *P = S.P;
     uint16_t *wpre = S.wpre;
-    uint32_t *flag = S.flag;
+    uint8_t *flag = S.flag;
     const uint64_t sidx = (uint64_t)bid * 2u + wave;
     uint8_t *out = scratch + sidx * slot_bytes;
 
@@ -348,7 +406,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         if (lane == 0) csize[sidx] = P[m] & 1u;
         return;
     }
-    uint32_t gop = 0, sop = 0, prev_end = 0;   // bytes written to global / staged; end of the last sequence
+    uint32_t gop = 0, sop = 0, prev_end = 0, qn = 0;   // bytes written to global / staged; end of the last sequence; queued coded ones
     int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
     for (int jw = -1; jw < (int)m; jw += 64) {
         BP_MARK("win_begin");
@@ -507,54 +565,40 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             sink += sel ? nxt : 0u;
             continue;
         }
-        // ---- sequences of the coded ones: match M (if hv) and tail run T over the zeros up to the next one
+        // ---- the coded ones that emit something — a match M (if hv) and / or a tail run T over the zeros up to the next
+        //      coded one — are queued; layout and emission run on 64 of them at a time (bp_emit_batch), every lane busy,
+        //      where the first version laid out and emitted per window with the ~30 % of its lanes that were coded ones
         const bool onM = sel && hv;
         const uint32_t rs = E + ((E == 0u || ((bp_bits(bm, E ? E - 1u : 0u) & 1u) != 0u)) ? 1u : 0u);
         uint32_t re = (uint32_t)P[(nxt < m ? nxt : m) + 1u] - 1u;   // position of the next one (n behind the last)
         re = re < BP_MATCHLIMIT ? re : BP_MATCHLIMIT;
         const bool onT = sel && (int)re - (int)rs >= BP_MINM && rs <= BP_MFLIMIT;
-        const uint32_t F = onT ? re : (onM ? E : 0u);
-        const uint32_t fincl = bp_scan_max(F, lane);
-        uint32_t pe = (uint32_t)__shfl_up(fincl, 1, 64);
-        pe = lane ? pe : 0u;
-        pe = pe > prev_end ? pe : prev_end;             // end of the previous sequence in stream order
-        uint32_t ms = (uint32_t)(q - (int)nb);
-        ms = onM ? (ms > pe ? ms : pe) : 0u;            // the previous sequence may have taken some of the zeros in front
-        const uint32_t llM = onM ? ms - pe : 0u, lenM = E - ms;
-        const uint32_t pe2 = onM ? E : pe;
-        const uint32_t llT = onT ? rs - pe2 : 0u, lenT = re - rs;
-        const uint32_t szM = onM ? 3u + bp_len_ext(llM) + llM + bp_len_ext(lenM - 4u) : 0u;
-        const uint32_t szT = onT ? 3u + bp_len_ext(llT) + llT + bp_len_ext(lenT - 4u) : 0u;
-        const uint32_t sincl = bp_scan_sum(szM + szT, lane);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
-        BP_MARK("sizes_done");
-        if (BP_SKIP >= 1) {
-            sink += total + sincl + ms + llT;
-            const uint32_t fm = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
-            prev_end = fm > prev_end ? fm : prev_end;
-            continue;
-        }
-        // the window's bytes go to the staging area; what is staged leaves in coalesced dwords when the next window
-        // would not fit (a window larger than the whole area is written to global memory directly)
-        BP_FENCE();
-        if (sop + total > BP_STAGE) {
-            bp_flush(S.stage, out + gop, sop, lane);
-            gop += sop;
-            sop = 0;
-        }
-        const uint32_t at = sincl - (szM + szT);
-        if (total > BP_STAGE) {   // (wave-uniform, rare: a window with hundreds of literals)
-            bp_put_seq(bm, out + gop, at, pe, ms, lenM, q1 - c1, onM, lane);
-            bp_put_seq(bm, out + gop, at + szM, pe2, rs, lenT, 1u, onT, lane);
-            gop += total;
-        } else {
-            bp_put_seq(bm, S.stage + sop, at, pe, ms, lenM, q1 - c1, onM, lane);
-            bp_put_seq(bm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
-            sop += total;
+        const bool want = onM || onT;
+        const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
+        const uint32_t nw = (uint32_t)__builtin_popcountll(wm);
+        const bool last = jw + 64 >= (int)m;
+        // one call site for the batch code: first make room if this window's coded ones would not fit (rare), then queue
+        // them, then drain whole batches (everything at the end)
+        for (int phase = 0; phase < 2; ++phase) {
+            if (phase == 1) {
+                const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                if (want) S.queue[slot] = bp_entry(E, (uint32_t)(q - (int)nb), onM, onT, rs, re, q1 - c1);
+                qn += nw;
+                BP_MARK("queued");
+            }
+            while (phase == 0 ? qn + nw > BP_QCAP : (qn >= 64u || (last && qn != 0u))) {   // (wave-uniform)
+                const uint32_t nb_ = qn < 64u ? qn : 64u;
+                BP_FENCE();
+                const BpOut r = bp_emit_batch(S, bm, out, nb_, BpOut{prev_end, gop, sop}, lane);
+                prev_end = r.prev_end, gop = r.gop, sop = r.sop;
+                BP_FENCE();
+                const uint2 mv = lane + 64u < qn ? S.queue[64u + lane] : make_uint2(0u, 0u);
+                BP_FENCE();
+                if (lane + 64u < qn) S.queue[lane] = mv;
+                qn -= nb_;
+            }
         }
         BP_MARK("emit_done");
-        const uint32_t fmax = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
-        prev_end = fmax > prev_end ? fmax : prev_end;
     }
     BP_MARK("loop_done");
     if (BP_SKIP >= 1) {

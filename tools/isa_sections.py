@@ -10,6 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+planes = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1: the plane-input instantiation, 0: int8 input
 out = "/tmp/lz4bits_marks.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-DBP_MARKS",
                        "-I", os.path.join(ROOT, "include"), "-o", out,
@@ -17,7 +18,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-
 inside, sec = False, "entry"
 cnt = collections.OrderedDict()
 for line in open(out):
-    if line.startswith(f"_Z15k_lz4_bitplanesILi{depth}E"):
+    if line.startswith(f"_Z15k_lz4_bitplanesILi{depth}ELb{planes}E"):
         inside = True
         continue
     if not inside:
