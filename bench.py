@@ -226,6 +226,8 @@ def correctness_gate(ctx, shards, S, blocksize):
         rec = sh.pending.wait()                      # raises on malformed text / capacity
         if rec.cursor_after != sh.V or rec.stats.n_kept != sh.V:
             raise AssertionError(f"{sh.contig}: kept {rec.stats.n_kept} of {sh.V} records")
+        if rec.stats.n_general_lines:
+            raise AssertionError(f"{sh.contig}: {rec.stats.n_general_lines} fixed-width lines took the variable-width path")
         lay = sh.layout
         if sh.res.P is not None:
             if rec.reserved:

@@ -250,7 +250,11 @@ __device__ __forceinline__ uint4 pl_load_line(const uint8_t *__restrict__ text, 
 {
     uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
     const uint64_t off = (uint64_t)soff + 4ull * ls;
-    if (!EDGE) {   // every lane owns four samples in front of the line's last one: the 16 bytes lie inside the line
+    if (!EDGE) {
+        // Every lane owns four samples in front of the line's last one: the 16 bytes lie inside the line.  (They start
+        // wherever the line's sample columns start; a wave-load whose lanes are not dword-aligned runs at ~80 % of an aligned
+        // one — tools/micro/strided_read.hip.  Loading aligned chunks and funnel-shifting with the neighbour lane's data was
+        // tried: correct, and no faster — the 65th chunk needs its own load per line, which costs what the alignment wins.)
         u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
         v = make_uint4(t.x, t.y, t.z, t.w);
     } else {

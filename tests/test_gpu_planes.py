@@ -266,6 +266,30 @@ def test_incompressible_planes_are_stored(ctx):
     assert np.array_equal(oracle.blosc_decompress(ck).view(np.int8).reshape(16, vc, 2), raw2[1])
 
 
+def test_sample_columns_beyond_2_gib(ctx):
+    """offsets into the text are 32-bit UNSIGNED: data lines that start behind 2 GiB of comment lines (a device kernel that
+    sign-extends an offset reads 4 GiB off — found the hard way with the aligned loads' scalar tail load)"""
+    S, V = 600, 700                                     # three bands of 256 samples: two of them take the aligned-load path
+    body, _ = synth.render_fixed_numpy("chr7", synth.variant_table(7, V, S), S, seed=7)
+    o = oracle.vcf_encode(body, S, region="chr7")
+    pad_line = torch.full((1 << 20,), ord("x"), dtype=torch.uint8, device=ctx.device)
+    pad_line[:2] = ord("#")
+    pad_line[-1] = 10
+    n_pad = 2100                                        # 2.2 GB of '#' lines of 1 MiB
+    text = torch.empty(n_pad * (1 << 20) + len(body) + 16, dtype=torch.uint8, device=ctx.device)
+    text[:n_pad << 20].view(n_pad, 1 << 20)[:] = pad_line
+    text[n_pad << 20:(n_pad << 20) + len(body)] = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(ctx.device)
+    text = text[:(n_pad << 20) + len(body)]
+    lay = dev.make_layout(S, 4096, sc=64, vc=4096)
+    res = _new_result(ctx, lay, with_g=False, poison=True)
+    cursor = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    rec = ctx.encode_text_planes_async(text, S, res, cursor, region="chr7", max_lines=V + n_pad + 64).wait()
+    assert rec.stats.n_kept == V == o["n_kept"] and rec.stats.n_general_lines == 0
+    ctx.pad_tail_planes(res, V, 0, 1)
+    assert np.array_equal(_dense_from_bytes(ctx.planes_expand(res), lay, V), o["G"])
+    del text
+
+
 def test_bad_layout_is_refused(ctx):
     lay = dev.make_layout(10, 1024, sc=64, vc=1024)
     assert dev.planes_bytes(lay) == 0
