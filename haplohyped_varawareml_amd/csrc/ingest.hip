@@ -205,7 +205,8 @@ struct hhgt_ingest {
     // file boundary
     struct InState {
         hhgt_layout lay;
-        DevBuf G, t_start, t_ref, t_alt, cursor;
+        DevBuf G, P, t_start, t_ref, t_alt, cursor;
+        bool planes = false;   // the ring holds the matrix as bit planes (include/hhgt.h "Bit-plane form"); G only backs calls beyond 0 / 1 / missing
         uint64_t ring_cols = 0, col_bytes = 0, n_sc = 0, chunk_nbytes = 0, kept_per_block = 0, done_cols = 0, host_cursor = 0;
     } ist[2];
     uint64_t n_begun = 0;
@@ -413,7 +414,28 @@ bool run_reader_input(hhgt_ingest *g, Input *in)
                 hhgt_set_error("%s: empty file (no VCF header)", in->path.c_str());
                 fail(g, HHGT_ERR_MALFORMED, hhgt_last_error());
                 ok = false;
+                break;
             }
+            // The reader may end a stream with an EMPTY last block (a gzip stream whose text fills a block exactly before
+            // zlib reports the end).  Blocks were already sent without `last`, so an empty one with last = true still has to go
+            // down the pipe: the harvest of THAT block pads and frames the open chunk column and sends INPUT_END — without it
+            // up to vc - 1 variants' genotypes would silently be missing behind their variant-table rows.
+            int ti;
+            if (!take_text(g, &ti, 64)) {
+                ok = false;
+                break;
+            }
+            TextBuf &tb = g->text[(size_t)ti];
+            if (hipEventRecord(tb.ready, g->s_copy) != hipSuccess) {
+                fail(g, HHGT_ERR_HIP, "ingest: event record failed");
+                ok = false;
+                break;
+            }
+            tb.nbytes = 0;
+            tb.in = in;
+            tb.first = false;
+            tb.last = true;
+            if (!push_text(g, ti)) ok = false;
             break;
         }
         if (first && !set_header(g, in, static_cast<const uint8_t *>(ptr), (size_t)n, last != 0)) {
@@ -851,14 +873,21 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     X->col_bytes = X->n_sc * X->chunk_nbytes;
     const uint64_t gbytes = hhgt_layout_bytes(&X->lay);
     G_TRY(X->G.ensure((size_t)(gbytes ? gbytes : 16)));
+    // the compressor is this engine's only consumer of the matrix: where the chunk geometry allows (typesize 2, 8 KiB Blosc
+    // blocks, whole blocks per chunk row) the encoder hands it over as bit planes — a quarter of the bytes each way
+    static const bool planes_env = !(getenv("HHGT_INGEST_PLANES") && atoi(getenv("HHGT_INGEST_PLANES")) == 0);
+    X->planes = planes_env && S > 0 && g->o.typesize == 2 && g->o.blocksize == 8192 && vc % 4096 == 0 && hhgt_planes_bytes(&X->lay) != 0;
+    if (X->planes) G_TRY(X->P.ensure((size_t)hhgt_planes_bytes(&X->lay)));
     G_TRY(X->t_start.ensure((size_t)X->lay.v_capacity * 4));
     G_TRY(X->t_ref.ensure((size_t)X->lay.v_capacity));
     G_TRY(X->t_alt.ensure((size_t)X->lay.v_capacity));
     G_TRY(X->cursor.ensure(8));
     // sample padding rows (S .. round_up(S, sc)) are never written by the encoder: zeroed once per input for every
     // ring column (everything else of a column is overwritten, or zeroed by the tail padding, before it is framed)
-    if (gbytes && S % (uint64_t)sc)
-        G_TRY(hhgt_pad_tail(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->G.p, g->s_main));
+    if (gbytes && S % (uint64_t)sc) {
+        if (X->planes) G_TRY(hhgt_pad_tail_planes(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->P.p, g->s_main));
+        else G_TRY(hhgt_pad_tail(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->G.p, g->s_main));
+    }
     G_HIP(hipMemsetAsync(X->cursor.p, 0, 8, g->s_main));
     X->done_cols = 0;
     X->host_cursor = 0;
@@ -930,8 +959,12 @@ bool queue_columns(hhgt_ingest *g, Input *in, uint64_t c0, uint64_t c1)
         if (!g->free_dst.pop(b.dst_slot) || !get_event(g, &b.ev)) return false;
         DstSlot &d = g->dst[(size_t)b.dst_slot];
         const int bs = g->o.blocksize;
-        G_TRY(hhgt_compress_chunks(g->ctx, X->G.as<uint8_t>() + slot * X->col_bytes, b.n_chunks, X->chunk_nbytes, g->o.typesize, bs,
-                                   g->o.format, d.d.p, d.d.cap, d.off.as<uint64_t>(), nullptr, g->s_main));
+        if (X->planes)
+            G_TRY(hhgt_compress_planes(g->ctx, &X->lay, X->P.p, X->G.p, (uint32_t)slot, (uint32_t)n, g->o.format, d.d.p, d.d.cap,
+                                       d.off.as<uint64_t>(), nullptr, g->s_main));
+        else
+            G_TRY(hhgt_compress_chunks(g->ctx, X->G.as<uint8_t>() + slot * X->col_bytes, b.n_chunks, X->chunk_nbytes, g->o.typesize, bs,
+                                       g->o.format, d.d.p, d.d.cap, d.off.as<uint64_t>(), nullptr, g->s_main));
         G_HIP(hipMemcpyAsync(d.h_off.p, d.off.p, (size_t)((b.n_chunks + 1) * 8), hipMemcpyDeviceToHost, g->s_main));
         G_HIP(hipEventRecord(b.ev, g->s_main));
         g->q_ship.push(b);
@@ -1037,7 +1070,8 @@ bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
         }
         if (last && b % (uint64_t)g->o.vc) {
             // the open column: zero behind the cursor, frame it
-            G_TRY(hhgt_pad_tail_cursor(g->ctx, &X->lay, X->cursor.as<uint64_t>(), X->G.p, g->s_main));
+            if (X->planes) G_TRY(hhgt_pad_tail_planes_cursor(g->ctx, &X->lay, X->cursor.as<uint64_t>(), X->P.p, g->s_main));
+            else G_TRY(hhgt_pad_tail_cursor(g->ctx, &X->lay, X->cursor.as<uint64_t>(), X->G.p, g->s_main));
             if (!queue_columns(g, in, X->done_cols, X->done_cols + 1)) return false;
             X->done_cols += 1;
         }
@@ -1088,10 +1122,16 @@ void driver_main(hhgt_ingest *g)
             const uint64_t n_regions = (tb.nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION;
             uint64_t max_lines = tb.nbytes / (2 * in->S_file + 17) + (tb.first ? in->header_lines : 0) + 64;
             if (max_lines > n_regions * INDEX_CAP) max_lines = n_regions * INDEX_CAP;
-            G_TRY(hhgt_encode_text_async(g->ctx, tb.d, tb.nbytes, in->region.c_str(), &X->lay, X->cursor.as<uint64_t>(),
-                                         (uint32_t)(max_lines > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : max_lines), X->G.p,
-                                         X->t_start.as<uint32_t>(), nullptr, X->t_ref.as<uint8_t>(), X->t_alt.as<uint8_t>(), r.rec,
-                                         g->s_main));
+            if (X->planes)
+                G_TRY(hhgt_encode_text_planes_async(g->ctx, tb.d, tb.nbytes, in->region.c_str(), &X->lay, X->cursor.as<uint64_t>(),
+                                                    (uint32_t)(max_lines > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : max_lines), X->P.p, X->G.p,
+                                                    X->t_start.as<uint32_t>(), nullptr, X->t_ref.as<uint8_t>(), X->t_alt.as<uint8_t>(),
+                                                    r.rec, g->s_main));
+            else
+                G_TRY(hhgt_encode_text_async(g->ctx, tb.d, tb.nbytes, in->region.c_str(), &X->lay, X->cursor.as<uint64_t>(),
+                                             (uint32_t)(max_lines > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : max_lines), X->G.p,
+                                             X->t_start.as<uint32_t>(), nullptr, X->t_ref.as<uint8_t>(), X->t_alt.as<uint8_t>(), r.rec,
+                                             g->s_main));
             G_HIP(hipEventRecord(r.ev, g->s_main));
             r.text_idx = ti;
             pending.push_back(next_res);
@@ -1430,7 +1470,7 @@ extern "C" void hhgt_ingest_close(hhgt_ingest *g)
     }
     g->crc_x2n.release();
     for (auto &x : g->ist)
-        for (DevBuf *b : {&x.G, &x.t_start, &x.t_ref, &x.t_alt, &x.cursor}) b->release();
+        for (DevBuf *b : {&x.G, &x.P, &x.t_start, &x.t_ref, &x.t_alt, &x.cursor}) b->release();
     for (auto &r : g->res) {
         if (r.rec) hipHostFree(r.rec);
         if (r.ev) hipEventDestroy(r.ev);

@@ -262,6 +262,26 @@ class Context:
             check(self.lib.hhgt_planes_expand(self.h, C.byref(lay), _ptr(res.P), _ptr(res.G), int(col0), int(n_cols), _ptr(out), _stream()))
         return out
 
+    def chrom_runs(self):
+        n = C.c_uint32(0)
+        check(self.lib.hhgt_encode_chrom_runs(self.h, 0, None, None, C.byref(n)))
+        if n.value == 0:
+            return []
+        first = np.zeros(n.value, np.uint64)
+        names = np.zeros((n.value, 32), np.uint8)
+        check(self.lib.hhgt_encode_chrom_runs(self.h, n.value, first.ctypes.data, names.ctypes.data, C.byref(n)))
+        return [(int(first[i]), bytes(names[i]).rstrip(b"\0").decode()) for i in range(n.value)]
+
+    def pad_tail(self, res, v_end=None, vcol_begin=0, vcol_end=None):
+        lay = res.layout
+        Vc = lay.vc or lay.v_capacity
+        v_end = res.n_kept if v_end is None else v_end
+        if vcol_end is None:
+            vcol_end = -(-max(v_end, 1) // Vc)
+        with torch.cuda.device(self.device):
+            check(self.lib.hhgt_pad_tail(self.h, C.byref(lay), int(v_end), int(vcol_begin), int(vcol_end),
+                                         _ptr(res.G), _stream()))
+
     def create_stream(self, kind):
         """kind "encode" | "compress": the stream pair for running compress of one block beside encode of the next
         (include/hhgt.h hhgt_stream_create: the compress stream is restricted to 3/4 of the CUs) -> torch ExternalStream,

@@ -225,3 +225,56 @@ def test_randomized_engine_matches_oracle(ctx, tmp_path, seed):
         for n, i in enumerate(sel):
             text, S, region = expect[i]
             check_against_oracle(res[n], text, S, region, sc, vc)
+
+
+@pytest.mark.parametrize("shape", ["fixed", "mixed"])
+def test_planes_geometry_matches_oracle(ctx, tmp_path, shape, fixture_text):
+    """default-like chunk geometry (vc a multiple of 4096, 8 KiB blocks, typesize 2): the engine keeps the ring as BIT PLANES
+    (include/hhgt.h "Bit-plane form") and compresses from them — same chunks as far as any decoder can tell.  Small text
+    blocks: tiles straddle the append position, ring slots are recycled, the open column is padded at the end."""
+    S, V, sc, vc = 300, 21000, 64, 4096
+    if shape == "fixed":
+        text, _ = synth.render_fixed_numpy("chr6", synth.variant_table(6, V, S), S, seed=6)
+    else:      # ./. and .|1 calls, '/' separators, GT:DP lines, dropped records
+        text = bytes(ctx.synth_mixed("chr6", synth.mixed_table(6, V, S), S, seed=6)[0].cpu().numpy())
+    p = str(tmp_path / "chr6.filtered.vcf.gz")
+    write_bgzf(p, text, level=1)
+    pf = str(tmp_path / "chr22.filtered.vcf.gz")
+    with gzip.open(pf, "wb") as f:
+        f.write(fixture_text)
+    res = run_engine(ctx, [(p, "chr6"), (pf, "chr22")], sc=sc, vc=vc, fmt=dev.BLOSC1, block_bytes=1 << 20, n_threads=3)
+    check_against_oracle(res[0], text, S, "chr6", sc, vc)
+    check_against_oracle(res[1], fixture_text, 3, "chr22", sc, vc)       # GT:GQ:DP columns: bits set by the variable-width kernel
+    assert res[0]["stats"]["n_blocks"] >= 5
+
+
+def test_gzip_stream_that_ends_on_a_block_boundary(ctx, tmp_path):
+    """a gzip stream whose text fills the reader's blocks exactly: the reader's last block is EMPTY (n = 0, last = 1).  The
+    engine must still pad and frame the open chunk column and end the input (it once broke out of the loop instead:
+    variant rows without genotypes, no INPUT_END)."""
+    S, L = 100, 1024
+    names = synth.sample_names(S)
+    head = synth.header_text("chr6", names)
+    pad = (-len(head)) % L
+    if pad < 8:
+        pad += L
+    head = b"##pad=" + b"x" * (pad - 7) + b"\n" + head           # the header block is a whole number of 1 KiB lines' worth
+    assert len(head) % L == 0
+    n_rec = (3 << 20) // L - len(head) // L                       # header + records = exactly 3 MiB = three reader blocks
+    rng = np.random.default_rng(1)
+    calls = rng.integers(0, 2, (n_rec, S, 2))
+    lines = []
+    for i in range(n_rec):
+        gt = "\t".join(f"{a}|{b}" for a, b in calls[i])
+        fixed = f"chr6\t{1000000 + 7 * i}\t.\tA\tC\t.\tPASS\t"
+        info = "P" * (L - len(fixed) - len("\tGT\t") - len(gt) - 1)
+        lines.append(f"{fixed}{info}\tGT\t{gt}\n")
+        assert len(lines[-1]) == L
+    text = head + "".join(lines).encode()
+    assert len(text) == 3 << 20
+    p = str(tmp_path / "chr6.filtered.vcf.gz")
+    with gzip.open(p, "wb", compresslevel=1) as f:
+        f.write(text)
+    r = run_engine(ctx, [(p, "chr6")], sc=64, vc=512, fmt=dev.BLOSC1, block_bytes=1 << 20, n_threads=2)[0]
+    check_against_oracle(r, text, S, "chr6", 64, 512)
+    assert r["stats"]["n_kept"] == n_rec and n_rec % 512 != 0     # the last column was open when the stream ended
