@@ -644,7 +644,9 @@ __device__ __forceinline__ uint32_t lz4_wave_compress_v6(const uint8_t *in, uint
 // MW = minimum waves per SIMD the register allocator must leave room for (0: no constraint, workgroups of up
 // to 16 waves for typesize 16).  The common genotype case (typesize 2 -> 2-wave workgroups) is latency bound,
 // so it is compiled for 8 resident waves per SIMD (<= 64 VGPRs).
-template <int MW, int ALGO>
+// PLANES: the blocks exist as bit planes (phase A generates the bytes); a template parameter so that the int8
+// instantiations keep their registers (the default one sits at the 72-register line of 7 waves per SIMD)
+template <int MW, int ALGO, bool PLANES>
 __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(const uint8_t *__restrict__ src, uint32_t nblocks,
                                                      uint64_t chunk_nbytes, uint32_t typesize, uint32_t blocksize,
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     const uint8_t *blk = src + chunk * chunk_nbytes + boff;
 
     // ---- phase A: load + byte-shuffle into LDS
-    if (planes) {
+    if (PLANES) {
         // the block exists as bit planes (include/hhgt.h "Bit-plane form"; typesize 2, 8 KiB blocks): the shuffled byte
         // planes are generated from the bits; bytes of calls beyond 0 / 1 / missing come from their place in src
         uint64_t pcol;
@@ -819,10 +821,12 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     }
     static size_t attr_lds = 64 * 1024;  // dynamic LDS above 64 KiB needs an explicit opt-in
     if (lds > attr_lds) {
-        const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1>), reinterpret_cast<const void *>(k_lz4_blocks<0, 5>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<8, 5>), reinterpret_cast<const void *>(k_lz4_blocks<0, 6>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<7, 6>), reinterpret_cast<const void *>(k_lz4_blocks<8, 6>),
-                             reinterpret_cast<const void *>(k_lz4_blocks<0, 7>), reinterpret_cast<const void *>(k_lz4_blocks<7, 7>)};
+        const void *fns[] = {reinterpret_cast<const void *>(k_lz4_blocks<0, 1, false>), reinterpret_cast<const void *>(k_lz4_blocks<0, 5, false>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<8, 5, false>), reinterpret_cast<const void *>(k_lz4_blocks<0, 6, false>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<7, 6, false>), reinterpret_cast<const void *>(k_lz4_blocks<8, 6, false>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<0, 7, false>), reinterpret_cast<const void *>(k_lz4_blocks<7, 7, false>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<8, 5, true>), reinterpret_cast<const void *>(k_lz4_blocks<7, 6, true>),
+                             reinterpret_cast<const void *>(k_lz4_blocks<7, 7, true>)};
         for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
@@ -842,18 +846,23 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     static const bool dbg = getenv("HHGT_LZ4_DEBUG") != nullptr;
     if (dbg) {  // development: what the runtime thinks fits on a CU
         int n7 = -1, n8 = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n7, k_lz4_blocks<7, 6>, (int)(64u * nwaves), lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, k_lz4_blocks<8, 6>, (int)(64u * nwaves), lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n7, k_lz4_blocks<7, 6, false>, (int)(64u * nwaves), lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, k_lz4_blocks<8, 6, false>, (int)(64u * nwaves), lds);
         fprintf(stderr, "[hhgt lz4] nwaves=%u hashlog=%u lds=%zu B/workgroup, workgroups per CU: <7,6> %d  <8,6> %d\n", nwaves, hashlog,
                 lds, n7, n8);
     }
-#define LZ_LAUNCH(MWV, ALG)                                                                                          \
-    hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks,   \
+#define LZ_LAUNCH2(MWV, ALG, PL)                                                                                      \
+    hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG, PL>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks, \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
                        (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked, d_planes, pg)
+#define LZ_LAUNCH(MWV, ALG) LZ_LAUNCH2(MWV, ALG, false)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)
-    if ((algo & 0xFFu) == 1u) LZ_LAUNCH(0, 1);
+    if (d_planes) {   // typesize 2: two-wave workgroups
+        if (fast == 1) LZ_LAUNCH2(8, 5, true);
+        else if (fast == 2) LZ_LAUNCH2(7, 7, true);
+        else LZ_LAUNCH2(7, 6, true);
+    } else if ((algo & 0xFFu) == 1u) LZ_LAUNCH(0, 1);
     else if (fast == 1 && nwaves <= 2) LZ_LAUNCH(8, 5);
     else if (fast == 1) LZ_LAUNCH(0, 5);
     else if (fast == 2 && nwaves <= 2) LZ_LAUNCH(7, 7);
@@ -861,6 +870,7 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     else if (mw == 8) LZ_LAUNCH(8, 6);
     else if (mw == 7) LZ_LAUNCH(7, 6);
     else LZ_LAUNCH(0, 6);
+#undef LZ_LAUNCH2
 #undef LZ_LAUNCH
     HIP_TRY(hipGetLastError());
     return HHGT_OK;

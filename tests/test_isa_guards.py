@@ -35,7 +35,7 @@ def lz4_asm(tmp_path_factory):
 def kernels(asm):
     """kernel name -> body text"""
     out = {}
-    for m in re.finditer(r"^(_Z12k_lz4_blocksILi\d+ELi\d+EE\w+):\s*;.*?$", asm, re.M):
+    for m in re.finditer(r"^(_Z12k_lz4_blocksILi\d+ELi\d+ELb[01]EE\w+):\s*;.*?$", asm, re.M):
         end = asm.index("s_endpgm", m.end())
         out[m.group(1)] = asm[m.end():end]
     return out
@@ -55,11 +55,11 @@ def test_parse_loop_masks_do_not_alias(lz4_asm):
 
 def test_queue_stays_in_lds_and_registers_fit(lz4_asm):
     ks = kernels(lz4_asm)
-    default = next(b for n, b in ks.items() if "ILi7ELi6E" in n)
+    default = next(b for n, b in ks.items() if "ILi7ELi6ELb0E" in n)
     assert "flat_store" not in default and "flat_load" not in default, "sequence queue reached through flat addressing"
     assert "ds_write_b64" in default                      # the exec-masked enqueue
     meta = lz4_asm[lz4_asm.index("amdhsa.kernels"):]
-    i = meta.index("k_lz4_blocksILi7ELi6E")
+    i = meta.index("k_lz4_blocksILi7ELi6ELb0E")
     chunk = meta[i:i + 1200]
     vgpr = int(re.search(r"\.vgpr_count:\s*(\d+)", chunk).group(1))
     spill = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", chunk).group(1))
