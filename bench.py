@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true", help="skip the host-fed / end-to-end legs")
     ap.add_argument("--legs-chroms", default="1,2,3,4", help="shards the host-fed / end-to-end legs run on")
     ap.add_argument("--no-check", action="store_true", help="skip the correctness gate")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C4 legs")
+    ap.add_argument("--only-config", default="", help="development: run only this config leg (C2 or C4[:variants]) and print it")
     ap.add_argument("--lz4-priority", action="store_true", help="development: the compress stream gets the high priority")
     ap.add_argument("--cu-split", default="", help="development: 'E,C' = the encode stream may use the first E CUs of the mask "
                                                    "order, the compress stream the last C (hipExtStreamCreateWithCUMask)")
@@ -433,6 +435,109 @@ def ingest_legs(ctx, shards, S, chroms, fmt):
         shutil.rmtree(d, ignore_errors=True)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the other GPU configurations of BASELINE.json (configs[1] = C2, configs[3] = C4) as legs of the same line
+# ---------------------------------------------------------------------------------------------------------------
+def config_leg(ctx, which, variants=None, steps=3):
+    """One pass of the hot path (encode -> pad -> compress, bit-plane intermediate, single stream, text resident in HBM) over
+    C2 = synthetic chr22, 50 000 variants x 1000 samples, biallelic phased, or
+    C4 = 500 000 variants x 5000 samples with multiallelic records (dropped by the reference's isSNP filter), ./. and .|1
+         calls, '/' separators and GT:DP columns; its text (11.5 GB) is rendered and encoded in pieces below 4 GiB.
+    Checked after the timed passes: kept counts against the generator's table, every chunk decoded on the GPU against the
+    expanded planes, sampled variants against the generator's call rule, one chunk through the CPU oracle."""
+    import numpy as np
+    import torch
+    from haplohyped_varawareml_amd import device as dev, synth
+    from oracle import oracle
+    d = ctx.device
+    if which == "C2":
+        S, V, contig, seed = 1000, variants or 50_000, "chr22", 22
+        tab = synth.variant_table(seed, V, S)
+        pieces = [ctx.synth_fixed(contig, tab, S, seed=seed)[0]]
+        kept = np.arange(V)
+    else:
+        S, V, contig, seed = 5000, variants or 500_000, "chr4", 4
+        tab = synth.mixed_table(seed, V, S)
+        kept = np.nonzero(tab["kept"])[0]
+        pieces, step_v = [], 100_000
+        for a in range(0, V, step_v):
+            sub = {k: (v[a:a + step_v] if isinstance(v, np.ndarray) and len(v) == V else v) for k, v in tab.items()}
+            pieces.append(ctx.synth_mixed(contig, sub, S, seed=seed, v_first=a, with_header=(a == 0))[0])
+    n_kept = len(kept)
+    lay = dev.make_layout(S, n_kept)
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=d)
+    cap = lay.v_capacity
+    res = dev.EncodeResult(None, lay, z(cap, torch.int32), None, z(cap, torch.uint8), z(cap, torch.uint8), 0, {}, [],
+                           z(dev.planes_bytes(lay), torch.uint8))
+    chunk_nbytes = lay.sc * lay.vc * 2
+    n_chunks = dev.layout_bytes(lay) // chunk_nbytes
+    dst = torch.empty(n_chunks * (chunk_nbytes + 32), dtype=torch.uint8, device=d)
+    off = z(n_chunks + 1, torch.int64)
+    cursor = z(1, torch.int64)
+    pend = [dev.PendingEncode() for _ in pieces]
+
+    def one_pass():
+        cursor.zero_()
+        for t, p in zip(pieces, pend):
+            ctx.encode_text_planes_async(t, S, res, cursor, max_lines=t.numel() // (2 * S + 17) + 64, region=contig, pending=p)
+        ctx.pad_tail_planes_cursor(res, cursor)
+        ctx.compress_planes(res, fmt=dev.BLOSC2, dst=dst, chunk_off=off, sync=False)
+
+    one_pass()
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stages = ctx.profile_read()
+    ctx.profile(False)
+    recs = [p.wait() for p in pend]
+    if int(cursor.item()) != n_kept or sum(r.stats.n_records for r in recs) != V or any(r.reserved for r in recs):
+        raise AssertionError(f"{which}: kept {int(cursor.item())} of {n_kept} expected, records {sum(r.stats.n_records for r in recs)} of {V}")
+    G = ctx.planes_expand(res)
+    back, bad = ctx.decompress(dst, off, n_chunks, chunk_nbytes, typesize=2, blocksize=8192)
+    if bad or not torch.equal(back, G):
+        raise AssertionError(f"{which}: decoded chunks differ from the expanded planes ({bad} chunks flagged)")
+    del back
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(n_kept, min(n_kept, 512), replace=False))
+    g = G.view(torch.int8).view(cap // lay.vc, -(-S // lay.sc), lay.sc, lay.vc, 2)
+    pk = torch.from_numpy(pick).to(d)
+    got = g[pk // lay.vc, :, :, pk % lay.vc, :].reshape(len(pick), -1, 2)[:, :S].permute(1, 0, 2).cpu().numpy()
+    if which == "C2":
+        want = np.stack([synth.genotype_bits(seed, int(v), 1, S, tab["thr"][v:v + 1])[0] for v in pick], axis=1).astype(np.int8)
+    else:
+        want = synth.mixed_expected_G(seed, tab, S, kept[pick])
+    if not np.array_equal(got, want):
+        raise AssertionError(f"{which}: sampled variants differ from the generator's calls")
+    k = n_chunks // 2
+    o2 = off[k:k + 2].cpu().numpy()
+    if not np.array_equal(oracle.blosc_decompress(dst[int(o2[0]):int(o2[1])].cpu().numpy()), G[k * chunk_nbytes:(k + 1) * chunk_nbytes].cpu().numpy()):
+        raise AssertionError(f"{which}: chunk {k} does not decode (oracle) to the matrix bytes")
+    comp = int(off[-1].item())
+    n_missing = int((G.view(torch.int8) == -9).sum().item())
+    # nonzero bytes per 4096-variant plane: what the bit-plane coders walk (more than 636: the byte-wise kernel's)
+    per_plane = (G.view(-1, lay.vc // 4096, 4096, 2) != 0).sum(dim=2).reshape(-1).float()
+    dense = float((per_plane > 636).float().mean().item())
+    out = {"workload": ("synthetic chr22, 50 000 variants x 1000 samples, biallelic phased (BASELINE configs[1])" if which == "C2" else
+                        "500 000 variants x 5000 samples, multiallelic + missing calls (BASELINE configs[3]); the reference's isSNP filter "
+                        "drops the multiallelic records") if not variants else f"{which} shape at {V} variants",
+           "value": V / dt, "unit": "variants/s", "ms_per_pass": dt * 1e3, "variants": V, "kept": n_kept, "samples": S,
+           "text_bytes": int(sum(t.numel() for t in pieces)), "general_lines": int(sum(r.stats.n_general_lines for r in recs)),
+           "missing_calls": n_missing, "compression_ratio": n_kept * 2 * S / max(comp, 1),
+           "nonzero_bytes_per_plane": {"mean": float(per_plane.mean().item()), "max": float(per_plane.max().item()),
+                                       "planes_left_to_the_byte_wise_coder": dense},
+           "stages_ms": {k_: v["ms"] / steps for k_, v in stages.items()},
+           "checked": f"{n_chunks} chunks decoded on the GPU, {len(pick)} variants against the generator, 1 chunk through the oracle",
+           "streams": 1}
+    del G, res, dst, pieces
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -462,6 +567,10 @@ def main():
     torch.cuda.set_device(local_rank)
     ctx = dev.Context(local_rank)
     ctx.set_clevel(args.clevel)
+    if args.only_config:
+        name, _, nv = args.only_config.partition(":")
+        print(json.dumps(config_leg(ctx, name, int(nv) if nv else None)))
+        return
     S = args.samples
     shards = build_shards(ctx, args, rank, world)
     my_variants = sum(sh.V for sh in shards)
@@ -612,6 +721,18 @@ def main():
                 out["host_fed"] = out["e2e"] = {"error": failed}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shards, S, args.cpu_seconds)
+        if not args.no_other_configs and not failed:
+            # the headline workload's buffers go first: C4's text alone is 11.5 GB
+            for sh in shards:
+                sh.text = sh.res = sh.dst = None
+            torch.cuda.empty_cache()
+            out["other_configs"] = {}
+            for name in ("C2", "C4"):
+                try:
+                    out["other_configs"][name] = config_leg(ctx, name)
+                except Exception as e:
+                    failed = f"{name} leg: {type(e).__name__}: {e}"
+                    out["other_configs"][name] = {"error": failed}
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out))

@@ -666,6 +666,11 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     // wave index through readfirstlane: everything derived from it (stream base, output slot) stays in SGPRs,
     // so the byte stores below use the SGPR-base + 32-bit-offset addressing form
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    if (only_marked) {   // a listed block whose streams have all been coded since (the exception-aware bit-plane coder): nothing to load
+        bool any = false;
+        for (uint32_t j = 0; j < nwaves; ++j) any = any || csize[(uint64_t)bid * nwaves + j] == 0xFFFFFFFFu;
+        if (!any) continue;   // (workgroup-uniform)
+    }
     const uint64_t chunk = bid / nblocks;
     const uint32_t b = bid - (uint32_t)(chunk * nblocks);
     const uint64_t boff = (uint64_t)b * blocksize;

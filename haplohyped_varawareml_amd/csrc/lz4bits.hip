@@ -53,8 +53,10 @@
 #define BP_MFLIMIT (BP_N - 12)
 #define BP_MATCHLIMIT (BP_N - 5)
 
-template <bool CHAIN> struct BpLds {
-    uint32_t bm[132];                // bit map of the plane: 128 dwords + zero padding
+template <bool CHAIN, bool EXC> struct BpLds {
+    uint32_t bm[132];                // bit map of the plane's nonzero bytes: 128 dwords + zero padding
+    uint32_t xm[EXC ? 132 : 1];      // EXC: which of them are 0xF7 (missing calls)
+    uint32_t cls[EXC ? 24 : 1];      // EXC: the same per ONE: bit i = the one with P-index i is a missing call
     uint32_t tab[1 << BP_HLOG];      // min(gap behind the one + 1, BP_GAPCLIP) -> one index + 1
     uint8_t flag[72];                // pointer-doubling marks of a window
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
@@ -132,11 +134,18 @@ __device__ __forceinline__ uint32_t bp_gap4(const uint32_t *gbw, uint32_t i)
 // kernel evaluates this eight times per window)
 __device__ __forceinline__ uint32_t bp_len_ext(uint32_t x) { return __umul24(x + 240u, 32897u) >> 23; }
 
+// literal bytes of positions whose map bits are b (and, EXC, whose missing-call bits are x): 0, 1 or 0xF7
+template <bool EXC> __device__ __forceinline__ uint32_t bp_lit(uint32_t b, uint32_t x, uint32_t k)
+{
+    const uint32_t v = (b >> k) & 1u;
+    return EXC ? (((x >> k) & 1u) ? 0xF7u : v) : v;
+}
+
 // one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off).  OUT is a pointer
 // into the staging area (LDS: ds_write_b8) or, for a window too large for it, into the stream's slot in global memory.
-template <typename OUT>
-__device__ __forceinline__ void bp_put_seq(const uint32_t *bm, OUT out, uint32_t at, uint32_t anchor, uint32_t start, uint32_t len,
-                                           uint32_t off, bool on, uint32_t lane)
+template <bool EXC, typename OUT>
+__device__ __forceinline__ void bp_put_seq(const uint32_t *bm, const uint32_t *xm, OUT out, uint32_t at, uint32_t anchor, uint32_t start,
+                                           uint32_t len, uint32_t off, bool on, uint32_t lane)
 {
     const uint32_t ll = on ? start - anchor : 0u, ml = len - 4u;
     const uint32_t llx = on ? bp_len_ext(ll) : 0u, mlx = on ? bp_len_ext(ml) : 0u;
@@ -153,11 +162,11 @@ __device__ __forceinline__ void bp_put_seq(const uint32_t *bm, OUT out, uint32_t
     // Longer runs (the literals of all the ones in between that code nothing pile up in front of the next sequence)
     // are written by the whole wave, one run at a time — a lockstep per-lane loop would run max(ll) times for all.
     if (__builtin_amdgcn_ballot_w64(ll != 0u) != 0ull) {
-        const uint32_t b = bp_bits(bm, anchor);
+        const uint32_t b = bp_bits(bm, anchor), x = EXC ? bp_bits(xm, anchor) : 0u;
         const bool small = ll <= 6u;
 #pragma unroll
         for (uint32_t k = 0; k < 6u; ++k)
-            if (small && k < ll) out[lit + k] = (uint8_t)((b >> k) & 1u);
+            if (small && k < ll) out[lit + k] = (uint8_t)bp_lit<EXC>(b, x, k);
         unsigned long long big = __builtin_amdgcn_ballot_w64(ll > 6u);
         while (big != 0ull) {
             const int l = __builtin_ctzll(big);
@@ -165,7 +174,7 @@ __device__ __forceinline__ void bp_put_seq(const uint32_t *bm, OUT out, uint32_t
             const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ll, l);
             const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)anchor, l);
             const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)lit, l);
-            for (uint32_t k = lane; k < n; k += 64u) out[dst + k] = (uint8_t)(bp_bits(bm, src + k) & 1u);
+            for (uint32_t k = lane; k < n; k += 64u) out[dst + k] = (uint8_t)bp_lit<EXC>(bp_bits(bm, src + k), EXC ? bp_bits(xm, src + k) : 0u, 0u);
         }
     }
     if (on) {
@@ -199,9 +208,10 @@ struct BpOut {
     uint32_t prev_end, gop, sop;   // end of the last sequence; bytes written to global / staged
 };   // (by value: a reference across the "memory" fences would pin the counters to scratch memory)
 
-template <typename LDS>
+template <bool EXC, typename LDS>
 __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8_t *__restrict__ out, uint32_t n, BpOut st, uint32_t lane)
 {
+    const uint32_t *xm = S.xm;
     uint32_t prev_end = st.prev_end, gop = st.gop, sop = st.sop;
     const bool have = lane < n;
     const uint2 en = have ? S.queue[lane] : make_uint2(0u, 0u);
@@ -229,12 +239,12 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
     }
     const uint32_t at = sincl - (szM + szT);
     if (total > BP_STAGE) {   // (wave-uniform, rare: a batch with hundreds of literals)
-        bp_put_seq(bm, out + gop, at, pe, ms, lenM, off, onM, lane);
-        bp_put_seq(bm, out + gop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+        bp_put_seq<EXC>(bm, xm, out + gop, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq<EXC>(bm, xm, out + gop, at + szM, pe2, rs, lenT, 1u, onT, lane);
         gop += total;
     } else {
-        bp_put_seq(bm, S.stage + sop, at, pe, ms, lenM, off, onM, lane);
-        bp_put_seq(bm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+        bp_put_seq<EXC>(bm, xm, S.stage + sop, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq<EXC>(bm, xm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
         sop += total;
     }
     prev_end = (uint32_t)__builtin_amdgcn_readlane((int)F, (int)(n - 1u));
@@ -249,18 +259,35 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
 // l / 4), and a set EXC bit is what "a byte > 1" was.  The pieces of four neighbouring sample rows share a 128-byte
 // line, so the blocks are dealt to the workgroups in an XCD-aware order: of 64 consecutive workgroups the eight that land
 // on one XCD (round robin) take eight consecutive blocks — one L2 fetches each line once.
-template <int DEPTH, bool PLANES>
-__global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
+// EXC (with PLANES): the exception-aware instantiation — planes whose bytes are 0, 1 or 0xF7 (missing calls; config 4).
+// It walks the list of blocks the plain instantiation queued (marked / n_marked) on a fixed grid and codes the streams
+// that one left marked; the bit map is the map of NONZERO bytes, a second map says which of them are 0xF7, every one
+// carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
+// Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
+template <int DEPTH, bool PLANES, bool EXC>
+__global__ __launch_bounds__(128, EXC ? 6 : 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
                                                           uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
                                                           uint32_t *__restrict__ marked, uint32_t *__restrict__ n_marked)
 {
-    const uint32_t bid = PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
-    if (PLANES && bid >= n_blocks) return;   // (the grid is rounded up to whole groups of 64)
+    static_assert(!EXC || PLANES, "the exception-aware coder reads bit planes");
     constexpr bool CHAIN = DEPTH > 1;
-    __shared__ BpLds<CHAIN> lds[2];
+    __shared__ BpLds<CHAIN, EXC> lds[2];
     __shared__ uint32_t nonbin[2][2];
     __shared__ uint32_t queued;   // the block goes into the byte-wise encoder's list once, whichever wave asks first
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    // EXC: `return` inside the body means "next block of the list" (the two waves of a workgroup are independent there)
+#define BP_DONE()               \
+    do {                        \
+        if (EXC) goto bp_next;  \
+        else return;            \
+    } while (0)
+    const uint32_t n_items = EXC ? *n_marked : 1u;
+    for (uint32_t item = EXC ? blockIdx.x : 0u; item < n_items; item += EXC ? gridDim.x : 1u) {
+    {
+    const uint32_t bid = EXC ? marked[item] : PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
+    if (PLANES && !EXC && bid >= n_blocks) return;   // (the grid is rounded up to whole groups of 64)
+    if (EXC && csize[(uint64_t)bid * 2u + wave] != 0xFFFFFFFFu) BP_DONE();   // coded by the plain instantiation
+    uint32_t xlo = 0, xhi = 0;   // EXC: the lane's 64 positions of the missing-call map
     uint32_t wlo, whi;
     bool nonbinary;
     if (PLANES) {
@@ -274,10 +301,21 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         whi = one.y;
         lds[wave].bm[2u * lane] = wlo;
         lds[wave].bm[2u * lane + 1u] = whi;
-        nonbinary = __builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) != 0ull;
         if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
-        if (threadIdx.x == 0) queued = 0u;
-        __syncthreads();   // (for `queued` only: each wave works on what it loaded itself)
+        if (EXC) {
+            // (ONE, EXC) = (0, 1): a call beyond 0 / 1 / missing, its byte lives in the int8 matrix — not this coder's
+            nonbinary = __builtin_amdgcn_ballot_w64(((exc.x & ~one.x) | (exc.y & ~one.y)) != 0u) != 0ull;
+            xlo = exc.x;
+            xhi = exc.y;
+            lds[wave].xm[2u * lane] = xlo;
+            lds[wave].xm[2u * lane + 1u] = xhi;
+            if (lane < 4u) lds[wave].xm[128u + lane] = 0u;
+            if (lane < 24u) lds[wave].cls[lane] = 0u;
+        } else {
+            nonbinary = __builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) != 0ull;
+            if (threadIdx.x == 0) queued = 0u;
+            __syncthreads();   // (for `queued` only: each wave works on what it loaded itself)
+        }
     } else {
     const uint8_t *blk = src + (uint64_t)bid * 8192u;
 
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     uint32_t sink = 0;
     if (BP_SKIP >= 5) {
         if (lane == 0) csize[(uint64_t)bid * 2u + wave] = lds[wave].bm[5] & 1u;
-        return;
+        BP_DONE();
     }
 
     // ---- phase B: wave w codes plane w
@@ -342,7 +380,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     // hand-over below is an access whose address it cannot tell apart from the lane's own writes, and BP_FENCE marks
     // the phase boundaries for good measure.  (volatile pointers would also do — and turn every access into a
     // serialised flat load with its own wait, which made this kernel 2x slower than it had to be.)
-    BpLds<CHAIN> &S = lds[wave];
+    BpLds<CHAIN, EXC> &S = lds[wave];
     uint32_t *bm = S.bm;
     uint16_t *P = S.P;
     uint16_t *wpre = S.wpre;
@@ -354,7 +392,8 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     const uint32_t incl = bp_scan_sum(cnt, lane);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (nonbinary || m > BP_MAXONES) {
-        if (lane == 0) {   // left to the byte-wise encoder: mark the stream, queue its block (once: two workgroups on one
+        if (EXC) BP_DONE();   // stays marked: the byte-wise kernel walks the same list next
+        if (lane == 0) {   // left to the next coder: mark the stream, queue its block (once: two workgroups on one
             csize[sidx] = 0xFFFFFFFFu;   // block would write two different valid encodings into the same slot)
             if (atomicExch(&queued, 1u) == 0u) marked[atomicAdd(n_marked, 1u)] = bid;
         }
@@ -372,14 +411,18 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         uint32_t base = 64u * lane + 1u;
         while (__builtin_amdgcn_ballot_w64(lo != 0u) != 0ull) {
             if (lo != 0u) {
-                P[at++] = (uint16_t)(base + (uint32_t)__builtin_ctz(lo));
+                const uint32_t bpos = (uint32_t)__builtin_ctz(lo);
+                if (EXC && ((xlo >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));   // (LDS: ds_or_b32)
+                P[at++] = (uint16_t)(base + bpos);
                 lo &= lo - 1u;
             }
         }
         base += 32u;
         while (__builtin_amdgcn_ballot_w64(hi != 0u) != 0ull) {
             if (hi != 0u) {
-                P[at++] = (uint16_t)(base + (uint32_t)__builtin_ctz(hi));
+                const uint32_t bpos = (uint32_t)__builtin_ctz(hi);
+                if (EXC && ((xhi >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));
+                P[at++] = (uint16_t)(base + bpos);
                 hi &= hi - 1u;
             }
         }
@@ -404,7 +447,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     BP_MARK("plist_done");
     if (BP_SKIP >= 4) {
         if (lane == 0) csize[sidx] = P[m] & 1u;
-        return;
+        BP_DONE();
     }
     uint32_t gop = 0, sop = 0, prev_end = 0, qn = 0;   // bytes written to global / staged; end of the last sequence; queued coded ones
     int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
@@ -419,9 +462,11 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
         // ---- candidate table: keyed on the gap behind the one; exact recency through the LDS's lane order
         const bool can = DEPTH > 0 && valid && j >= 0 && q + 12 <= BP_N;
         uint32_t jc1 = 0;
+        // EXC: classes of this one (bit 0) and of the four ones behind it
+        const uint32_t c5a = EXC ? (bp_bits(S.cls, jj) & 31u) : 0u;
         if (can) {
             const uint32_t g1 = qn1 - q1;
-            const uint32_t idx = g1 < BP_GAPCLIP ? g1 : BP_GAPCLIP;
+            const uint32_t idx = (g1 < BP_GAPCLIP ? g1 : BP_GAPCLIP) ^ ((EXC && (c5a & 1u)) ? 63u : 0u);
             jc1 = atomicExch(&S.tab[idx], (uint32_t)(j + 1));
             if (CHAIN) S.chain[jj] = (uint16_t)jc1;   // what this one replaced: the next candidate down the chain
         }
@@ -448,12 +493,19 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
                 uint32_t nextc = 0;
                 if (CHAIN) nextc = S.chain[jq];
                 const uint32_t x = (a4 ^ b4) | stop4;
-                const uint32_t k = (uint32_t)__builtin_ctz(x) >> 3;                     // agreeing gaps: 0..3
+                uint32_t k = (uint32_t)__builtin_ctz(x) >> 3;                           // agreeing gaps: 0..3
+                bool same = true;
+                if (EXC) {   // ... of which only those count whose next ones are of the same class; the first byte must agree at all
+                    const uint32_t xc = c5a ^ (bp_bits(S.cls, jq) & 31u);
+                    same = (xc & 1u) == 0u;
+                    const uint32_t tv = (uint32_t)__builtin_ctz((xc >> 1) | 8u);
+                    k = k < tv ? k : tv;
+                }
                 const uint32_t below = (1u << (8u * k)) - 1u;
                 const uint32_t sumg = __builtin_amdgcn_sad_u8(a4 & below, 0u, k + 1u);  // their zeros + their ones + this one
                 const uint32_t za = (a4 >> (8u * k)) & 0xFFu, zb = (b4 >> (8u * k)) & 0xFFu;
                 const int score = (int)(sumg + (za < zb ? za : zb));
-                if (have && score > best) {
+                if (have && same && score > best) {
                     best = score;
                     bjq = jq;
                     bk = k;
@@ -481,7 +533,8 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
                     if (act) {
                         const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
                         costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
-                        if (s < BP_PICK || ga != gb || ga >= 255u || a >= m || s >= BP_STEPS) {
+                        const bool cdiff = EXC && (((bp_bits(S.cls, a + 1u) ^ bp_bits(S.cls, b + 1u)) & 1u) != 0u);
+                        if (s < BP_PICK || ga != gb || ga >= 255u || a >= m || s >= BP_STEPS || cdiff) {
                             const uint32_t z = ga < gb ? ga : gb;
                             clen += 1u + z;
                             tailz = ga - z;
@@ -589,7 +642,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
             while (phase == 0 ? qn + nw > BP_QCAP : (qn >= 64u || (last && qn != 0u))) {   // (wave-uniform)
                 const uint32_t nb_ = qn < 64u ? qn : 64u;
                 BP_FENCE();
-                const BpOut r = bp_emit_batch(S, bm, out, nb_, BpOut{prev_end, gop, sop}, lane);
+                const BpOut r = bp_emit_batch<EXC>(S, bm, out, nb_, BpOut{prev_end, gop, sop}, lane);
                 prev_end = r.prev_end, gop = r.gop, sop = r.sop;
                 BP_FENCE();
                 const uint2 mv = lane + 64u < qn ? S.queue[64u + lane] : make_uint2(0u, 0u);
@@ -603,7 +656,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     BP_MARK("loop_done");
     if (BP_SKIP >= 1) {
         if (lane == 0) csize[sidx] = (prev_end + sink) & 0xFFFu;
-        return;
+        BP_DONE();
     }
     // ---- last literals
     {
@@ -624,7 +677,8 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
                     r -= 255u;
                 }
             }
-            for (uint32_t k = lane; k < ll; k += 64u) dstp[1u + llx + k] = (uint8_t)(bp_bits(bm, prev_end + k) & 1u);
+            for (uint32_t k = lane; k < ll; k += 64u)
+                dstp[1u + llx + k] = (uint8_t)bp_lit<EXC>(bp_bits(bm, prev_end + k), EXC ? bp_bits(S.xm, prev_end + k) : 0u, 0u);
         };
         if (direct) {
             tail(out + gop);
@@ -636,7 +690,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     }
     uint32_t op = gop + sop;
     if (op >= BP_N) {   // incompressible: Blosc stores the (shuffled) stream verbatim
-        for (uint32_t k = lane; k < BP_N; k += 64u) out[k] = (uint8_t)(bp_bits(bm, k) & 1u);
+        for (uint32_t k = lane; k < BP_N; k += 64u) out[k] = (uint8_t)bp_lit<EXC>(bp_bits(bm, k), EXC ? bp_bits(S.xm, k) : 0u, 0u);
         op = BP_N;
     } else {
         BP_FENCE();
@@ -644,6 +698,10 @@ __global__ __launch_bounds__(128, 8) void k_lz4_bitplanes(const uint8_t *__restr
     }
     if (BP_SKIP) op = (op & 0xFFFu) + (sink & 1u);
     if (lane == 0) csize[sidx] = op;
+    }
+bp_next:;
+    }
+#undef BP_DONE
 }
 
 int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
@@ -658,13 +716,22 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint6
     // development: extra (unused) dynamic LDS per workgroup caps how many workgroups a CU holds, which leaves LDS and
     // wave slots to a kernel running beside this one on another stream
     static const int lds_pad = getenv("HHGT_LZ4_LDS_PAD") ? atoi(getenv("HHGT_LZ4_LDS_PAD")) : 0;
+    // the exception-aware instantiation walks the list the plain one queued, on a grid that fills the chip (HHGT_LZ4_EXC=0:
+    // every marked stream goes to the byte-wise kernel, as before round 3)
+    static const bool exc_env = !(getenv("HHGT_LZ4_EXC") && atoi(getenv("HHGT_LZ4_EXC")) == 0);
+    const uint32_t exc_grid = (uint32_t)(n_blocks < 256u * 12u ? n_blocks : 256u * 12u);
 #define BP_LAUNCH2(D, PL)                                                                                                   \
-    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
+    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL, false>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
                        d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked)
-#define BP_LAUNCH(D)            \
-    do {                        \
-        if (planes) BP_LAUNCH2(D, true); \
-        else BP_LAUNCH2(D, false);       \
+#define BP_LAUNCH(D)                                                                                                        \
+    do {                                                                                                                    \
+        if (planes) {                                                                                                       \
+            BP_LAUNCH2(D, true);                                                                                            \
+            if (exc_env)                                                                                                    \
+                hipLaunchKernelGGL((k_lz4_bitplanes<D, true, true>), dim3(exc_grid), dim3(128), 0, st, d_src, pg, (uint32_t)n_blocks, d_scratch, \
+                                   (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked);                                    \
+        } else                                                                                                              \
+            BP_LAUNCH2(D, false);                                                                                           \
     } while (0)
     if (depth <= 0) BP_LAUNCH(0);
     else if (depth == 1) BP_LAUNCH(1);

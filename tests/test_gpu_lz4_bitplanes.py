@@ -153,15 +153,16 @@ def test_edge_planes(ctx, ref):
 
 
 def test_non_binary_and_dense_planes_fall_back(ctx, ref):
-    """a byte > 1 (missing call -9 = 0xF7) or more than 636 ones: the byte-wise encoder codes the stream — mixed
-    with bit-plane streams in the same block and chunk"""
+    """int8 input: a byte > 1 (missing call -9 = 0xF7) or more than 636 ones: the byte-wise encoder codes the stream — mixed
+    with bit-plane streams in the same block and chunk.  (From the bit-plane form, planes with missing calls have their own
+    instantiation of the coder: the tests further down.)"""
     rng = np.random.default_rng(9)
     planes = bench_like(rng, 16)
     planes[3, 100] = 0xF7
     planes[4, rng.integers(0, N, 300)] = 0xF7
     planes[7] = rng.integers(0, 2, N)
     planes[10] = rng.integers(0, 256, N)
-    assert ref(planes[3]) is None and ref(planes[7]) is None
+    assert ref(planes[10]) is None and ref(planes[7]) is None
     got, _ = run_planes(ctx, planes)
     for k, pl in enumerate(planes):
         back = pl if got[k].size == N else oracle.lz4_decompress(got[k], N)
@@ -188,3 +189,92 @@ print(total)
         env = dict(os.environ, HHGT_LZ4_BITPLANES=v)
         sizes.append(int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.split()[-1]))
     assert sizes[0] != sizes[1] and 0.8 < sizes[0] / sizes[1] < 1.25
+
+
+# ---- the exception-aware instantiation: planes with missing calls (bytes 0 / 1 / 0xF7), from the bit-plane form -----------
+def planes_to_tile_major(planes):
+    """byte planes [2 rows][4096] (plane 2r = haplotype 0 of sample row r, 2r + 1 = haplotype 1) -> (tile-major plane bytes
+    of ONE chunk column of 4096 variants, the int8 bytes they stand for) as include/hhgt.h documents the layout"""
+    planes = np.asarray(planes, np.uint8)
+    rows = planes.shape[0] // 2
+    P = np.zeros((16, 4, rows, 32), np.uint8)                      # [tile][kind-plane][row][32 B]
+    for h in range(2):
+        pl = planes[h::2]                                           # [rows][4096]
+        one = np.packbits((pl != 0).reshape(rows, 16, 256), axis=2, bitorder="little")       # [rows][16][32]
+        exc = np.packbits((pl == 0xF7).reshape(rows, 16, 256), axis=2, bitorder="little")
+        P[:, h] = one.transpose(1, 0, 2)
+        P[:, 2 + h] = exc.transpose(1, 0, 2)
+    raw = np.empty((rows, N, 2), np.uint8)
+    raw[:, :, 0] = planes[0::2]
+    raw[:, :, 1] = planes[1::2]
+    return P.reshape(-1), raw.reshape(-1)
+
+
+def run_planes_from_bits(ctx, planes):
+    rows = len(planes) // 2
+    assert rows & (rows - 1) == 0
+    P, raw = planes_to_tile_major(planes)
+    lay = dev.make_layout(rows, N, sc=rows, vc=N)
+    res = dev.EncodeResult(None, lay, None, None, None, None, 0, {}, [], torch.from_numpy(P).cuda())
+    assert np.array_equal(ctx.planes_expand(res).cpu().numpy(), raw)
+    dst, off, total = ctx.compress_planes(res, fmt=dev.BLOSC1)
+    chunk = dst[:total].cpu().numpy()
+    assert np.array_equal(oracle.blosc_decompress(chunk), raw), "chunk does not decode to the input"
+    return streams_of(chunk, 2, 8192, raw.size), total
+
+
+def with_missing(rng, planes, frac):
+    """a fraction of all positions becomes a missing call (0xF7), wherever it falls"""
+    out = planes.copy()
+    out[rng.random(planes.shape) < frac] = 0xF7
+    return out
+
+
+@pytest.mark.parametrize("scale,frac,seed", [(1.0, 0.025, 11), (1.0, 0.002, 12), (0.25, 0.025, 13), (1.0, 0.0, 14), (2.0, 0.05, 15)])
+def test_planes_with_missing_calls_match_the_reference(ctx, ref, scale, frac, seed):
+    rng = np.random.default_rng(seed)
+    planes = with_missing(rng, bench_like(rng, 128, scale), frac)
+    got, total = run_planes_from_bits(ctx, planes)
+    n_ref = n_exc = 0
+    for k, pl in enumerate(planes):
+        want = ref(pl)
+        assert np.array_equal(oracle.lz4_decompress(got[k], N) if got[k].size < N else got[k], pl)
+        if want is None or want.size >= N:      # left to the byte-wise encoder / stored verbatim
+            continue
+        n_ref += 1
+        n_exc += bool((pl == 0xF7).any())
+        assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref ({got[k].size} vs {want.size} bytes)"
+    assert n_ref >= (100 if scale <= 1 else 40)
+    if frac >= 0.002:
+        assert n_exc >= n_ref // 2               # most planes really went through the exception-aware instantiation
+
+
+def test_missing_call_edge_planes_match_the_reference(ctx, ref):
+    """the edge planes of the 0/1 coder with every k-th nonzero byte turned into a missing call, all-missing planes, runs of
+    missing calls, a missing call at either end"""
+    out = []
+    for a in edge_planes():
+        b = a.copy()
+        nz = np.flatnonzero(b)
+        b[nz[::3]] = 0xF7
+        out.append(b)
+    z = np.zeros(N, np.uint8)
+    for pos in ([0], [N - 1], [0, N - 1], list(range(100, 400)), list(range(0, N, 9))):
+        a = z.copy()
+        a[pos] = 0xF7
+        out.append(a)
+    a = z.copy()
+    a[::7] = 1
+    a[::21] = 0xF7                                                   # a period of classes on top of a period of gaps
+    out.append(a)
+    while len(out) & (len(out) - 1) or len(out) % 2:                 # rows must be a power of two
+        out.append(z.copy())
+    got, _ = run_planes_from_bits(ctx, out)
+    n_ref = 0
+    for k, pl in enumerate(out):
+        want = ref(pl)
+        if want is None or want.size >= N:
+            continue
+        n_ref += 1
+        assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref ({got[k].size} vs {want.size} bytes)"
+    assert n_ref >= 25

@@ -3,8 +3,12 @@
 // ratio studied without a GPU (tools/sim/gapenc.c is the exploration this came out of).  Not part of the product and
 // not an oracle of the reference: whether a stream is VALID is checked by decoding it (liblz4 / oracle decoder).
 //
-// Input: a plane of n = 4096 bytes, all 0 or 1.  Walks the ONES q_0 < q_1 < ... (a virtual one at -1 in front and
-// one at n behind).  P[j+1] = q_j + 1.  For every one j:
+// Input: a plane of n = 4096 bytes, all 0 or 1 — or, for the exception-aware instantiation of the kernel (planes with
+// missing calls, config 4), 0, 1 or 0xF7 (-9).  Walks the NONZERO bytes ("ones") q_0 < q_1 < ... (a virtual one at -1 in
+// front and one at n behind).  P[j+1] = q_j + 1; cls[j+1] = 1 if byte q_j is 0xF7.  A match copies bytes, so two ones
+// only agree if their classes do: the table key carries the class of the one, a candidate of the other class is passed
+// over, and a run of agreeing gaps ends in front of the first pair of ones whose classes differ (the zeros of that gap
+// still agree).  On 0/1 planes every class is 0 and nothing changes.  For every one j:
 //   * key = min(distance to the next one, 40), a 64-entry table of one indices; the table is updated one by one in
 //     stream order (on the GPU: one ds_wrxchg_rtn_b32 per 64 ones — the LDS serves equal addresses in lane order);
 //     what an insertion replaces is remembered (chain), so `depth` candidates can be tried per one: the table's entry,
@@ -56,12 +60,15 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
 {
     static __thread int chain[4100];
     static __thread int P[4096 + 4];
+    static __thread uint8_t cls[4096 + 32];
     int m = 0;
     P[0] = 0;
+    memset(cls, 0, sizeof(cls));
     for (int i = 0; i < n; ++i) {
-        if (in[i] > 1) return -1;
+        if (in[i] > 1 && in[i] != 0xF7) return -1;
         if (in[i]) {
             if (m >= N_MAXONES) return -1;
+            cls[1 + m] = in[i] == 0xF7;
             P[1 + m++] = i + 1;
         }
     }
@@ -83,7 +90,7 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
         int hv = 0, len = 0, nb = 0, c = 0;
         if (depth > 0 && j >= 0 && q + 12 <= n) {
             const uint32_t g1 = (uint32_t)(P[j + 2] - P[j + 1]);
-            const uint32_t idx = g1 < GAPCLIP ? g1 : GAPCLIP;
+            const uint32_t idx = (g1 < GAPCLIP ? g1 : GAPCLIP) ^ (cls[j + 1] ? 63u : 0u);
             int jc = (int)tab[idx] - 1;
             tab[idx] = (uint32_t)(j + 1);
             chain[j] = jc;
@@ -92,7 +99,8 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
             int best_score = -1, bj = -1, bk = 0;
             for (int dpt = 0; dpt < depth && jc >= 0; ++dpt, jc = chain[jc]) {
                 int k = 0, score = 0;
-                while (k < PICK && GB[j + 1 + k] == GB[jc + 1 + k] && GB[j + 1 + k] != 255) {
+                if (cls[jc + 1] != cls[j + 1]) continue;   // the first byte would differ
+                while (k < PICK && GB[j + 1 + k] == GB[jc + 1 + k] && GB[j + 1 + k] != 255 && cls[j + 2 + k] == cls[jc + 2 + k]) {
                     score += GB[j + 1 + k] + 1;
                     ++k;
                 }
@@ -113,7 +121,7 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
                 for (int s = bk;; ++s) {
                     const int ga = P[a + 2] - P[a + 1] - 1, gb = P[b + 2] - P[b + 1] - 1;
                     costR += 1 + (ga >= MINM + 1 ? 4 : ga);
-                    if (s < PICK || ga != gb || ga >= 255 || a + 1 >= m || s >= STEPS) {   // s < PICK: the pick's own verdict
+                    if (s < PICK || ga != gb || ga >= 255 || a + 1 >= m || s >= STEPS || cls[a + 2] != cls[b + 2]) {   // s < PICK: the pick's own verdict
                         const int z = ga < gb ? ga : gb;
                         clen += 1 + z;
                         tailz = ga - z;
