@@ -22,9 +22,12 @@ outside `value`, rank 0 at N = 1 also reports
 Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks
 time); shards are independent, there is no data-path collective.  `--gpus N` without a launcher starts the
 N ranks itself (before this process touches a GPU); under torchrun the given environment is used.  Default
-"weak": every rank encodes its own 3 M-variant cohort (different seeds).  --scaling strong splits the 22
-shards of ONE cohort over the ranks (longest-processing-time-first), as the north star's per-chromosome
-sharding does.
+"strong": the 22 shards of ONE cohort are dealt to the ranks longest-processing-time-first, as the north star's
+per-chromosome sharding does (`value` = 3 M variants x steps over the slowest rank's time); the trivially linear
+weak form (every rank its own cohort) is measured in the same run and reported as the secondary field `weak`.
+The end-to-end legs run on EVERY rank at once, each over its own share of the 22 BGZF files with its share of the
+host CPUs (sharding.pin_rank: the CPUs of its GPU's NUMA node, divided among the ranks), and are reported as the
+aggregate.
 """
 import argparse
 import json
@@ -46,7 +49,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--variants", type=int, default=3_000_000)
     ap.add_argument("--samples", type=int, default=2504)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): the 22 shards of ONE cohort are dealt to the ranks, longest first — the north star's "
+                         "per-chromosome sharding; weak: every rank encodes a cohort of its own")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1, --scaling strong: skip the secondary weak-scaling measurement")
     ap.add_argument("--vc", type=int, default=8192, help="variants per chunk (chunk = 64 x vc x 2 bytes)")
     ap.add_argument("--blocksize", type=int, default=8192, help="Blosc2 block bytes")
     ap.add_argument("--clevel", type=int, default=5, help="codec level (reference: 5); 1-2 = run-only fast mode")
@@ -58,7 +64,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU work of each baseline shape")
     ap.add_argument("--no-legs", action="store_true", help="skip the host-fed / end-to-end legs")
-    ap.add_argument("--legs-chroms", default="1,2,3,4", help="shards the host-fed / end-to-end legs run on")
+    ap.add_argument("--legs-chroms", default="all", help="shards the end-to-end legs run on (default: every shard of the rank)")
+    ap.add_argument("--fed-chroms", default="1,2,3,4", help="shards of the host-fed leg (their text is pinned in host memory)")
     ap.add_argument("--no-check", action="store_true", help="skip the correctness gate")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C4 legs")
     ap.add_argument("--only-config", default="", help="development: run only this config leg (C2 or C4[:variants]) and print it")
@@ -353,83 +360,126 @@ def cpu_baseline(shards, S, target_s):
 # ---------------------------------------------------------------------------------------------------------------
 # host-fed and end-to-end legs (rank 0, N = 1): the ingest engine on a bounded set of shards
 # ---------------------------------------------------------------------------------------------------------------
-def ingest_legs(ctx, shards, S, chroms, fmt):
+def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce_device, host):
+    """SURVEY.md §8d (ii) and (iii) through the native ingest engine, on THIS rank's shards, all ranks at once; every pass
+    is bracketed by a barrier and the slowest rank's time counts.  No best-of: the first pass (engine cold: its pinned
+    staging is still to be allocated) and the second (steady) are reported separately.  Files live in /dev/shm."""
     import shutil
     import tempfile
     import torch
+    from haplohyped_varawareml_amd import sharding
     from haplohyped_varawareml_amd.ingest import Columns, Ingest, InputEnd
     from haplohyped_varawareml_amd.reader import write_bgzf_native
-    pick = [sh for sh in shards if sh.chrom in chroms]
-    if not pick:
-        return None, None
-    V = sum(sh.V for sh in pick)
-    text_bytes = sum(sh.nbytes for sh in pick)
-    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    pick = [sh for sh in shards if e2e_chroms is None or sh.chrom in e2e_chroms]
+    fed = [sh for sh in shards if sh.chrom in fed_chroms]
+    if world > 1 and not fed:       # a rank without any of the named shards feeds its own largest ones, ~9 GB at most
+        acc = 0
+        for sh in sorted(shards, key=lambda x: -x.nbytes):
+            if acc + sh.nbytes <= 9.5e9:
+                fed.append(sh)
+                acc += sh.nbytes
+    d = tempfile.mkdtemp(prefix="hhgt_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def agg(seconds, units):
+        return sharding.reduce_job(dist, seconds, units, device=reduce_device)
+
     try:
         t0 = time.perf_counter()
-        hosts, files = [], []
+        hosts = {}
+        files = []
         for sh in pick:
-            h = torch.empty(sh.nbytes, dtype=torch.uint8).pin_memory()
+            h = torch.empty(sh.nbytes, dtype=torch.uint8)
+            if sh in fed:
+                h = h.pin_memory()
+                hosts[sh.chrom] = h
             h.copy_(sh.text)
-            hosts.append(h)
             p = os.path.join(d, f"{sh.contig}.filtered.vcf.gz")
-            write_bgzf_native(p, h.numpy(), level=6)
+            write_bgzf_native(p, h.numpy(), level=6, n_threads=host["n_threads"] if world > 1 else 0)
             files.append(p)
+            del h
+        for sh in fed:                      # (a fed shard outside the e2e set)
+            if sh.chrom not in hosts:
+                hosts[sh.chrom] = torch.empty(sh.nbytes, dtype=torch.uint8).pin_memory()
+                hosts[sh.chrom].copy_(sh.text)
         prep = time.perf_counter() - t0
         file_bytes = sum(os.path.getsize(p) for p in files)
 
         def h2d_rate():
-            dd = torch.empty(hosts[0].numel(), dtype=torch.uint8, device=ctx.device)
+            if not fed:
+                return 0.0
+            h0 = hosts[fed[0].chrom]
+            dd = torch.empty(h0.numel(), dtype=torch.uint8, device=ctx.device)
             torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(3):
-                dd.copy_(hosts[0], non_blocking=True)
+                dd.copy_(h0, non_blocking=True)
             torch.cuda.synchronize()
-            return 3 * hosts[0].numel() / (time.perf_counter() - t) / 1e9
+            return 3 * h0.numel() / (time.perf_counter() - t) / 1e9
 
         link = h2d_rate()
+        n_threads = host["n_threads"] if world > 1 else 0      # N ranks: each its share of the granted CPUs
 
-        def run(jobs, device_inflate, passes=3):
-            with Ingest(ctx, fmt=fmt, device_inflate=device_inflate) as ing:
-                best = None
-                first = None
+        def run(jobs, device_inflate, want_v, passes=2):
+            out = []
+            with Ingest(ctx, fmt=fmt, device_inflate=device_inflate, n_threads=n_threads) as ing:
                 for _ in range(passes):
+                    sync_all()
                     t = time.perf_counter()
                     for src, sh in jobs:
                         ing.add_file(src, sh.contig) if isinstance(src, str) else ing.add_memory(src, sh.contig)
                     framed = kept = n_end = 0
-                    for ev in ing.events():
-                        if isinstance(ev, Columns):
-                            framed += ev.framed.size
-                        elif isinstance(ev, InputEnd):
-                            kept += ev.stats["n_kept"]
-                            n_end += 1
-                            if n_end == len(jobs):
-                                break
+                    if jobs:
+                        for ev in ing.events():
+                            if isinstance(ev, Columns):
+                                framed += ev.framed.size
+                            elif isinstance(ev, InputEnd):
+                                kept += ev.stats["n_kept"]
+                                n_end += 1
+                                if n_end == len(jobs):
+                                    break
                     dt = time.perf_counter() - t
-                    if kept != V:
-                        raise AssertionError(f"ingest leg kept {kept} of {V} records")
-                    first = first if first is not None else dt
-                    best = dt if best is None or dt < best else best
-            return best, first, framed
+                    if kept != want_v:
+                        raise AssertionError(f"ingest leg kept {kept} of {want_v} records")
+                    dt_max, kept_all = agg(dt, kept)
+                    out.append((dt_max, kept_all, framed))
+            return out
 
-        what = f"chr{','.join(str(sh.chrom) for sh in pick)} of the cohort: {V} variants x {S} samples, {text_bytes / 1e9:.2f} GB of text"
-        tb, tf, framed = run([(h, sh) for h, sh in zip(hosts, pick)], False)
-        host_fed = {"value": V / tb, "unit": "variants/s", "text_GBps": text_bytes / tb / 1e9, "pinned_h2d_GBps": link,
-                    "frac_of_h2d": text_bytes / tb / 1e9 / link, "seconds": tb, "first_pass_seconds": tf,
-                    "sample": what + ", in pinned host memory -> 64 MiB blocks -> hipMemcpyAsync -> encode + compress -> framed chunks "
-                                     "copied back to pinned memory (ingest engine warm: best of 3 passes)",
-                    "ratio": V * S * 2 / max(framed, 1)}
-        e2e = {"sample": what + f", as {len(files)} BGZF level-6 files in /dev/shm ({file_bytes / 1e6:.0f} MB) -> framed chunks in "
-                                f"pinned host memory (ingest engine warm: best of 3 passes; first pass = with the engine's pinned staging "
-                                f"still to be allocated)", "file_bytes": file_bytes, "prep_seconds": prep,
-               "host_cpus": effective_cpus()}
-        for name, devinf in (("host_inflate", False), ("device_inflate", True)):
-            tb, tf, framed = run([(p, sh) for p, sh in zip(files, pick)], devinf)
-            e2e[name] = {"value": V / tb, "unit": "variants/s", "text_GBps": text_bytes / tb / 1e9, "seconds": tb,
-                         "first_pass_seconds": tf, "file_GBps": file_bytes / tb / 1e9,
-                         "inflater": "hhgt_reader: own DEFLATE decoder (csrc/fast_inflate.h, zlib as fallback) + PCLMUL CRC-32 on the granted host CPUs -> pinned ring -> hipMemcpyAsync"
-                         if not devinf else "k_inflate_members + k_crc32_members on the device (compressed members cross PCIe)"}
+        def leg(res, text_bytes_all, extra):
+            (t1, v_all, _), (t2, _, framed) = res[0], res[-1]
+            return dict({"value": v_all / t2, "unit": "variants/s", "seconds": t2, "text_GBps": text_bytes_all / t2 / 1e9,
+                         "first_pass": {"value": v_all / t1, "seconds": t1}, "variants": int(v_all)}, **extra)
+
+        _, fed_bytes_all = agg(0.0, sum(sh.nbytes for sh in fed))
+        _, e2e_bytes_all = agg(0.0, sum(sh.nbytes for sh in pick))
+        _, file_bytes_all = agg(0.0, file_bytes)
+        _, link_all = agg(0.0, link)
+        r = run([(hosts[sh.chrom], sh) for sh in fed], False, sum(sh.V for sh in fed))
+        host_fed = leg(r, fed_bytes_all, {
+            "pinned_h2d_GBps": link_all, "frac_of_h2d": fed_bytes_all / r[-1][0] / 1e9 / max(link_all, 1e-9),
+            "ratio": sum(sh.V for sh in fed) * S * 2 / max(r[-1][2], 1),
+            "sample": f"chr{','.join(str(sh.chrom) for sh in fed)} of this rank ({world} rank(s) at once): text in pinned host memory -> "
+                      f"64 MiB blocks -> hipMemcpyAsync -> encode + compress -> framed chunks copied back to pinned memory; "
+                      f"second (steady) pass, the first is reported beside it"})
+        e2e = {"sample": f"every shard of the cohort ({len(pick)} BGZF level-6 files on this rank, {world} rank(s) at once, "
+                         f"{int(e2e_bytes_all / 1e9)} GB of text in {file_bytes_all / 1e6:.0f} MB of files in /dev/shm) -> framed chunks in "
+                         f"pinned host memory; second (steady) pass, the first (engine cold) beside it; no best-of",
+               "file_bytes": int(file_bytes_all), "prep_seconds": prep, "host_cpus_granted": host["granted"],
+               "reader_threads_per_rank": n_threads or host["n_threads"], "numa_node": host["numa_node"],
+               "default_policy": "device_inflate='auto' (pipeline.stream_files, the converter): BGZF files that compress >= 2:1 "
+                                 "take the device inflater — the leg below named device_inflate IS that default; host "
+                                 "(device_inflate=False / HHGT_DEVICE_INFLATE=0) is the north star's design"}
+        want = sum(sh.V for sh in pick)
+        for name, mode in (("host_inflate", False), ("device_inflate", "auto")):
+            r = run([(p, sh) for p, sh in zip(files, pick)], mode, want)
+            e2e[name] = leg(r, e2e_bytes_all, {
+                "file_GBps": file_bytes_all / r[-1][0] / 1e9,
+                "inflater": "hhgt_reader: own DEFLATE decoder (csrc/fast_inflate.h, zlib as fallback) + PCLMUL CRC-32 on the granted host CPUs -> pinned ring -> hipMemcpyAsync"
+                if mode is False else "k_inflate_members + k_crc32_members on the device (compressed members cross PCIe), chosen by the default 'auto' policy"})
         return host_fed, e2e
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -565,6 +615,9 @@ def main():
         else:
             dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
+    # this rank's share of the host (N > 1: pinned to the CPUs of its GPU's NUMA node, divided among the ranks; the engine's
+    # reader threads inherit the mask and get host["n_threads"] of them)
+    host = sharding.pin_rank(rank, world, local_rank)
     ctx = dev.Context(local_rank)
     ctx.set_clevel(args.clevel)
     if args.only_config:
@@ -701,7 +754,11 @@ def main():
                    "variants_per_gpu": my_variants, "samples": S, "text_bytes_per_gpu": text_bytes,
                    "chunk": f"64 samples x {args.vc} variants x 2 int8, Blosc2 block {args.blocksize} B, typesize 2 (byte-shuffle), LZ4 clevel {args.clevel}",
                    "compression_ratio": g_bytes / max(comp_bytes, 1),
-                   "parallelism": f"per-chromosome shards x{world}, no collective"
+                   "shards_per_gpu": len(shards), "host_cpus": {"granted": host["granted"], "threads_per_rank": host["n_threads"],
+                                                                "numa_node": host["numa_node"], "pinned_cpus": len(host["cpus"])},
+                   "parallelism": f"per-chromosome shards x{world} ({args.scaling}: "
+                                  + ("the 22 shards of one cohort dealt longest-first" if args.scaling == "strong" else "a cohort per rank")
+                                  + "), no collective"
                                   + (f" ({backend}: {world} ranks on {n_dev} GPU: a rehearsal, not a scaling measurement)" if shared_gpu else ""),
                    "intermediate": "bit planes, 2 bits per allele (include/hhgt.h)" if planes else "int8 matrix",
                    "streams": 1 if args.no_overlap else 2,
@@ -711,14 +768,39 @@ def main():
         "stages_ms_per_step": {k: v["ms"] for k, v in stages_serial.items()},
         "stages_ms_per_step_timed_region": {k: v["ms"] / args.steps for k, v in stages.items()},
     }
+    dist_or_none = dist if use_dist else None
+    # what follows is collective: a rank whose gate failed takes everybody out of it
+    any_failed = sharding.reduce_job(dist_or_none, 1.0 if failed else 0.0, 0.0, device=dev_for_reduce)[0] > 0
+    if not any_failed and not args.no_legs:
+        try:
+            e2e_chroms = None if args.legs_chroms == "all" else {int(x) for x in args.legs_chroms.split(",") if x}
+            fed_chroms = {int(x) for x in args.fed_chroms.split(",") if x}
+            out["host_fed"], out["e2e"] = ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, dev.BLOSC2, dist_or_none, world,
+                                                      dev_for_reduce, host)
+        except Exception as e:
+            failed = f"ingest legs: {type(e).__name__}: {e}"
+            out["host_fed"] = out["e2e"] = {"error": failed}
+    if not any_failed and world > 1 and args.scaling == "strong" and not args.no_weak:
+        # secondary: weak scaling — every rank its own 3 M-variant cohort (trivially linear; here so that both shapes
+        # come from one run)
+        for sh in shards:
+            sh.text = sh.res = sh.dst = None
+        torch.cuda.empty_cache()
+        wargs = argparse.Namespace(**dict(vars(args), scaling="weak"))
+        wshards = build_shards(ctx, wargs, rank, world)
+        one_step(ctx, wshards, S, args.blocksize, streams, args.lookahead)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(ctx, wshards, S, args.blocksize, streams, args.lookahead)
+        barrier()
+        wdt, wv = sharding.reduce_job(dist_or_none, time.perf_counter() - t0, sum(sh.V for sh in wshards), device=dev_for_reduce)
+        out["weak"] = {"value": wv * args.steps / wdt, "unit": "variants/s", "ms_per_step": wdt / args.steps * 1e3,
+                       "variants_per_gpu": sum(sh.V for sh in wshards), "scaling": "weak",
+                       "note": "every rank encodes its own cohort (different seeds): per-GPU work fixed"}
+        del wshards
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not failed:
-        if not args.no_legs:
-            try:
-                chroms = {int(x) for x in args.legs_chroms.split(",") if x}
-                out["host_fed"], out["e2e"] = ingest_legs(ctx, shards, S, chroms, dev.BLOSC2)
-            except Exception as e:
-                failed = f"ingest legs: {type(e).__name__}: {e}"
-                out["host_fed"] = out["e2e"] = {"error": failed}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shards, S, args.cpu_seconds)
         if not args.no_other_configs and not failed:

@@ -79,7 +79,8 @@ class Ingest:
         self.L = _L()
         self.ctx = ctx
         o = IngestOpts(int(sc), int(vc), int(typesize), int(blocksize), int(fmt), int(bool(sites_only)),
-                       int(bool(device_inflate)), int(n_threads or 0), int(block_bytes or 0), int(files_ahead), 0)
+                       (2 if device_inflate == "auto" else int(bool(device_inflate))), int(n_threads or 0), int(block_bytes or 0),
+                       int(files_ahead), 0)
         h = C.c_void_p()
         check(self.L.hhgt_ingest_open(ctx.h, C.byref(o), C.byref(h)))
         self.h = h

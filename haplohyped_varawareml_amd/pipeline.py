@@ -221,8 +221,15 @@ class RawColumns:
 
 
 def _want_device_inflate(device_inflate):
+    """False: the host reader inflates (the north star's design, always selectable); True: BGZF files are inflated on the
+    device; "auto" (the default; HHGT_DEVICE_INFLATE=0|1|auto overrides): BGZF files that compress at least 2:1 take the
+    device — their compressed members are the smaller load for the host-device link, which bounds the host path at cohort
+    widths — everything else the host reader (include/hhgt_ingest.h)"""
     if device_inflate is None:
-        return os.environ.get("HHGT_DEVICE_INFLATE", "0") not in ("", "0")
+        device_inflate = os.environ.get("HHGT_DEVICE_INFLATE", "auto")
+    if isinstance(device_inflate, str):
+        v = device_inflate.strip().lower()
+        return "auto" if v == "auto" else v not in ("", "0", "false", "no", "host")
     return bool(device_inflate)
 
 
@@ -293,7 +300,7 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
     fs = FileStats()
     d = ctx.device
     device_inflate = _want_device_inflate(device_inflate)
-    if device_inflate and _is_bgzf_file(path):
+    if device_inflate and _is_bgzf_file(path):   # ("auto" in this single-file form: every BGZF file)
         # one wave per member: a launch wants >= 10 k members (64 KiB of text each) to fill the chip, so the text
         # block is 1 GiB unless the file is smaller (measured: 64 MiB blocks 1.4 M variants/s, 1 GiB 4.0 M)
         rd = _DeviceBgzfBlocks(ctx, path, block_bytes)

@@ -71,6 +71,26 @@ def merge_stores(parts, final_path, group_order):
     return final_path
 
 
+def wait_workers(procs, poll=0.2):
+    """joins the worker processes; as soon as one has exited non-zero the others are ended (they would otherwise sit in a
+    collective until its timeout).  -> exit codes of the workers that failed"""
+    live = list(procs)
+    failed = False
+    while live:
+        for p in list(live):
+            p.join(timeout=poll)
+            if p.exitcode is not None:
+                live.remove(p)
+                failed = failed or p.exitcode != 0
+        if failed:
+            for p in live:          # the processes this function was given, by handle — never by name or pattern
+                p.terminate()
+            for p in live:
+                p.join(timeout=30)
+            live = []
+    return [p.exitcode for p in procs if p.exitcode != 0]
+
+
 def _default_stream():
     from .pipeline import stream_files
     return stream_files
@@ -87,6 +107,10 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
     if make_ctx is None:
         from .device import Context
         make_ctx = Context
+    # this rank's share of the host: its reader threads (the engine starts `n_threads` per open file) stay on the CPUs of
+    # its GPU's NUMA node and the N ranks of a node do not oversubscribe it (N x --cores threads before)
+    from .sharding import pin_rank
+    host = pin_rank(rank, world, device if make_ctx is None or world > 1 else None, conv.cores)
     ctx = make_ctx(device)
     writer = StoreWriter(part_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=conv.cohort_name,
                          donor_ids=[d for d in conv.donor_ids if d], chunk_format="blosc1")
@@ -110,14 +134,15 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
         writer.end_group()
         conv.stats[group] = fs
         stats[group] = dict(n_kept=fs.n_kept, n_samples=fs.n_samples, n_lines=fs.n_lines, seconds=fs.seconds,
-                            raw_bytes=fs.raw_bytes, compressed_bytes=fs.compressed_bytes, rank=rank, device=device)
+                            raw_bytes=fs.raw_bytes, compressed_bytes=fs.compressed_bytes, rank=rank, device=device,
+                            n_threads=host["n_threads"], cpus=host["cpus"], numa_node=host["numa_node"])
         logger.info(f"[gpu {device}] chr{chromosomes[i]}: {fs.n_kept} SNPs x {fs.n_samples} samples in {fs.seconds:.2f}s "
                     f"({fs.n_lines / max(fs.seconds, 1e-9):.0f} lines/s), ratio "
                     f"{fs.raw_bytes / max(fs.compressed_bytes, 1):.2f}")
 
     try:
         if jobs:
-            stream_fn(ctx, jobs, sc=writer.meta["sc"], vc=writer.meta["vc"], n_threads=conv.cores or 0, fmt=BLOSC1,
+            stream_fn(ctx, jobs, sc=writer.meta["sc"], vc=writer.meta["vc"], n_threads=host["n_threads"], fmt=BLOSC1,
                       on_header=on_header, on_variants=lambda i, a, b, c: writer.add_variants(a, b, c),
                       on_columns=lambda i, g, n, framed: writer.add_chunks(framed[0], framed[1], g.numel()), on_end=on_end)
         writer.close()
@@ -137,7 +162,10 @@ def worker_entry(rank, world, port, cfg, stream_fn=None, make_ctx=None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
     conv = VCFtoHDF5Converter(cfg["cohort_name"], cfg["vcf_dir"], cfg["out_dir"], cfg["sample_list_path"], cfg["cores"],
                               cfg["cxx_threads"], n_gpus=world)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    # a rank that dies hard (segfault, GPU fault) never reaches the collectives: the others give up after 10 minutes
+    # instead of gloo's default 30, and run() ends them as soon as it sees the dead one
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     try:
         n_dev = torch.cuda.device_count() if make_ctx is None else world
         device = rank % max(n_dev, 1)
@@ -284,10 +312,10 @@ class VCFtoHDF5Converter:
                 procs = [ctx.Process(target=worker_entry, args=(r, world, port, cfg)) for r in range(world)]
                 for p in procs:
                     p.start()
-                for p in procs:
-                    p.join()
-                bad = [p.exitcode for p in procs if p.exitcode != 0]
+                bad = wait_workers(procs)
                 if bad:
+                    for part in cfg["parts"]:
+                        shutil.rmtree(part, ignore_errors=True)
                     raise RuntimeError(f"vcf_to_h5: {len(bad)} of {world} GPU workers failed (exit codes {bad})")
                 self.stats_by_group = json.load(open(os.path.join(self.store_path, "ranks.json")))["groups"]
                 logger.info(f"{world} GPU workers: plan {cfg['plan']}")

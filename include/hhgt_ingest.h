@@ -38,7 +38,10 @@ typedef struct {
     int32_t blocksize;      /* Blosc block bytes, 0 = min(vc * 2, 8192)                                            */
     int32_t format;         /* HHGT_BLOSC1 (what HDF5 filter 32001 stores) or HHGT_BLOSC2; 0 = HHGT_BLOSC2          */
     int32_t sites_only;     /* 1: ignore sample columns (load_vcf_without_sample, cpp/parse_vcf.cpp:80-113)         */
-    int32_t device_inflate; /* 1: BGZF files are inflated on the device; everything else takes the host reader     */
+    int32_t device_inflate; /* 0: the host reader inflates (the north star's design); 1: BGZF files are inflated on the
+                               device; 2 = auto: BGZF files whose first member inflates to >= 2x its size take the
+                               device (the compressed members are then the smaller load for the link, which is what
+                               bounds the host path at cohort widths); non-BGZF input always takes the host reader  */
     int32_t n_threads;      /* host inflate threads per open file (0 = the reader's default)                       */
     uint64_t block_bytes;   /* text block size; 0 = 64 MiB (host reader / memory) or 512 MiB (device inflate)         */
     int32_t files_ahead;    /* inputs opened ahead of the one being uploaded (host reader), 0 = 1                   */

@@ -68,6 +68,13 @@ def test_two_ranks_equal_single_process(tmp_path, golden_dir, fixture_golden):
     ranks = json.load(open(os.path.join(two.store_path, "ranks.json")))
     assert ranks["world"] == 2 and sorted(ranks["groups"]) == ["chr_22", "chr_4", "chr_7"]
     assert {g["rank"] for g in ranks["groups"].values()} == {0, 1}
+    # the host is dealt to the ranks: disjoint CPU sets, and each rank's reader-thread budget is its share of --cores
+    # (2 // 2) — not the whole host per rank, which is what 8 ranks x all CPUs would have been
+    by_rank = {g["rank"]: g for g in ranks["groups"].values()}
+    assert not set(by_rank[0]["cpus"]) & set(by_rank[1]["cpus"])
+    assert set(by_rank[0]["cpus"]) | set(by_rank[1]["cpus"]) <= set(os.sched_getaffinity(0))
+    assert all(g["n_threads"] == 1 for g in by_rank.values())
+    assert all(1 <= g["n_threads"] <= len(g["cpus"]) for g in by_rank.values())
     os.remove(os.path.join(two.store_path, "ranks.json"))
     assert not os.path.exists(cfg["parts"][0]) and not os.path.exists(cfg["parts"][1])
     _same_tree(one.store_path, two.store_path)
@@ -111,3 +118,49 @@ def test_merge_rejects_mismatched_headers(tmp_path):
         w.close()
     with pytest.raises(RuntimeError, match="sample columns differ"):
         vcf_to_h5.merge_stores([str(tmp_path / "p0"), str(tmp_path / "p1")], str(tmp_path / "m"), ["chr_1", "chr_2"])
+
+
+def test_cpu_partition_rules():
+    """sharding.partition_cpus: disjoint shares, NUMA-local where the topology is known, nobody without a CPU"""
+    from haplohyped_varawareml_amd.sharding import _parse_cpulist, partition_cpus
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(64))
+    # no topology: an even split
+    shares = [partition_cpus(allowed, 8, r) for r in range(8)]
+    assert all(len(s) == 8 for s in shares) and sorted(sum(shares, [])) == allowed
+    # two sockets of 32, GPUs 0-3 on node 0 and 4-7 on node 1: every rank stays on its GPU's socket
+    node_of = [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus_of = lambda n: list(range(32 * n, 32 * n + 32))
+    shares = [partition_cpus(allowed, 8, r, node_of, cpus_of) for r in range(8)]
+    assert all(len(s) == 8 for s in shares) and sorted(sum(shares, [])) == allowed
+    assert all(set(shares[r]) <= set(cpus_of(node_of[r])) for r in range(8))
+    # a restricted affinity mask (a container that grants CPUs 0-15 only): node 1 has no allowed CPU, its ranks share the rest
+    shares = [partition_cpus(list(range(16)), 4, r, [0, 0, 1, 1], cpus_of) for r in range(4)]
+    assert all(shares) and len({c for s in shares for c in s}) == sum(len(s) for s in shares)
+    # one rank's node unknown
+    shares = [partition_cpus(allowed, 4, r, [0, None, 1, 1], cpus_of) for r in range(4)]
+    assert len({c for s in shares for c in s}) == sum(len(s) for s in shares) and all(shares)
+    assert set(shares[0]) <= set(cpus_of(0)) and set(shares[2]) <= set(cpus_of(1))
+    # fewer CPUs than ranks: shared
+    assert partition_cpus([0, 1], 4, 3) == [0, 1]
+
+
+def test_dead_worker_ends_the_others(tmp_path):
+    """vcf_to_h5.wait_workers: one worker that dies hard (no collective reached) must not leave the job waiting for the
+    gloo timeout — the survivors are ended as soon as the death is seen"""
+    import time
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sleep_or_die, args=(r,)) for r in range(3)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    bad = vcf_to_h5.wait_workers(procs)
+    assert time.time() - t0 < 60 and len(bad) >= 1 and all(p.exitcode is not None for p in procs)
+
+
+def _sleep_or_die(rank):
+    import os
+    import time
+    if rank == 1:
+        os._exit(7)
+    time.sleep(600)
