@@ -8,6 +8,13 @@
 #include "../../include/hhgt.h"
 
 #define HHGT_WAVE 64
+// development (-DHHGT_ENC_PRIO=n): the memory-bound kernels of the encode chain raise their waves' issue priority, so that
+// beside the (VALU-bound) LZ4 kernel of the other stream their few instructions go out first
+#ifdef HHGT_ENC_PRIO
+#define HHGT_WAVE_PRIO() __builtin_amdgcn_s_setprio(HHGT_ENC_PRIO)
+#else
+#define HHGT_WAVE_PRIO()
+#endif
 
 // ---- error plumbing -------------------------------------------------------------------------
 void hhgt_set_error(const char *fmt, ...);

@@ -492,6 +492,7 @@ __global__ __launch_bounds__(64 * PT_NW, EDGE ? 2 : PT_WGS) void k_encode_planes
                                                           uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
                                                           DevCounters *cnt, uint32_t band0)
 {
+    HHGT_WAVE_PRIO();
     __shared__ __attribute__((aligned(16))) uint32_t img[1024 * PT_ROWDW];   // 32 KiB
     const uint64_t v_base = *d_cursor;
     const uint32_t n_kept = (uint32_t)cnt->n_kept;

@@ -71,6 +71,9 @@ static bool build_table(const uint8_t *lens, int nsyms, int tbits, uint32_t *tab
     if (left > 0 && (need_complete || used != 1)) {
         if (need_complete || used > 1) return false;
     }
+    // an incomplete alphabet of ONE code is only what zlib (the arbiter of what is valid here) accepts when that code is
+    // one bit long: anything else goes back to zlib, which rejects the stream
+    if (left > 0 && used == 1 && count[1] != 1) return false;
     uint32_t next[MAX_BITS + 2];
     uint32_t code = 0;
     for (int l = 1; l <= MAX_BITS; ++l) {

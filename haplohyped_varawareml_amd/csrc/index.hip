@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
                                                         uint32_t *__restrict__ counts, uint32_t n_regions,
                                                         DevCounters *cnt)
 {
+    HHGT_WAVE_PRIO();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (r >= n_regions) return;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
                                                    uint32_t *__restrict__ counts, uint32_t n_regions, uint32_t skip,
                                                    DevCounters *cnt)
 {
+    HHGT_WAVE_PRIO();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     const uint32_t r_first = w * HOP_K;
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void k_compact_newlines(const uint32_t *__rest
                                                           uint32_t n_regions, uint32_t *__restrict__ nl,
                                                           uint32_t max_lines)
 {
+    HHGT_WAVE_PRIO();
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
     uint32_t c = counts[r], p = prefix[r];
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ l_flags, uint32_t *__restrict__ l_keep,
                                                      uint32_t *__restrict__ l_cnew, DevCounters *cnt)
 {
+    HHGT_WAVE_PRIO();
     // The walk below is byte-serial per line; straight from global memory that is ~80 dependent loads per lane with
     // every wave of the grid resident at once, i.e. the kernel lasts one full latency chain (89 us for 136 k lines).
     // So the first 64 bytes of every line (CHROM .. FORMAT of a typical record) are fetched up front by four
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     uint32_t max_runs, const uint64_t *__restrict__ d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *__restrict__ d_start,
     uint32_t *__restrict__ d_stop, uint8_t *__restrict__ d_ref, uint8_t *__restrict__ d_alt, DevCounters *cnt)
 {
+    HHGT_WAVE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_found = *d_nlines;
     const uint32_t n_lines = n_found < max_lines ? n_found : max_lines;

@@ -883,6 +883,8 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     const uint64_t S = in->S;
     const int32_t sc = g->o.sc, vc = g->o.vc;
     // a kept line holds S sample columns of at least two bytes behind nine fixed columns
+    // (file inputs: the reader never hands out blocks below 1 MiB and grows a text buffer to what a block needs)
+    if (block_bytes < (1ull << 20)) block_bytes = 1ull << 20;
     X->kept_per_block = block_bytes / (2 * in->S_file + 16) + 2;
     const uint64_t W = X->kept_per_block / (uint64_t)vc + 2;   // chunk columns one block can touch
     X->ring_cols = 2 * W + 6;
@@ -1058,6 +1060,12 @@ bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
     in->st.n_blocks += 1;
     const uint64_t a = rec.cursor_before, b = rec.cursor_after;
     const bool last = tb.last;
+    if (b - a > X->kept_per_block) {   // the ring and the variant slots were sized from this bound: never trust it silently
+        hhgt_set_error("ingest: a text block kept %llu records, the engine's buffers were sized for %llu (block of %llu bytes)",
+                       (unsigned long long)(b - a), (unsigned long long)X->kept_per_block, (unsigned long long)tb.nbytes);
+        fail(g, HHGT_ERR_CAPACITY, hhgt_last_error());
+        return false;
+    }
     g->free_text.push(r.text_idx);   // the text has been consumed: the source may overwrite the buffer
     r.text_idx = -1;
     X->host_cursor = b;

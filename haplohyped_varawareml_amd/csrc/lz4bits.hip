@@ -34,9 +34,14 @@
 #include "common.h"
 
 #define BP_N 4096
+#ifndef BP_MAXONES
 #define BP_MAXONES 636
+#endif
 #ifndef BP_STAGE
 #define BP_STAGE 576    // staging area; with the queue below the workgroup stays under 11 KiB of LDS = 14 workgroups per CU
+#endif
+#ifndef BP_WAVES
+#define BP_WAVES 7       // waves per SIMD the plain instantiations are compiled for (LDS must allow 2 x BP_WAVES workgroups per CU)
 #endif
 #define BP_QCAP 100     // queued coded ones a wave can hold (a window adds at most 64 to fewer than 64)
 #define BP_HLOG 6
@@ -265,7 +270,7 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
 // carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
 // Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
 template <int DEPTH, bool PLANES, bool EXC>
-__global__ __launch_bounds__(128, EXC ? 6 : 8) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
+__global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
                                                           uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
                                                           uint32_t *__restrict__ marked, uint32_t *__restrict__ n_marked)
 {

@@ -41,6 +41,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ in, uint64_t n,
                                                             uint32_t *__restrict__ partial)
 {
+    HHGT_WAVE_PRIO();
     __shared__ uint32_t sm[8];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     uint32_t s = 0;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__re
 // single block: exclusive scan of partial[0..nb) in place, partial[nb] = grand total
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(uint32_t *partial, uint32_t nb)
 {
+    HHGT_WAVE_PRIO();
     __shared__ uint32_t sm[8];
     uint32_t carry = 0;
     for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_down(const uint32_t *__rest
                                                           const uint32_t *__restrict__ partial, uint32_t nb,
                                                           uint32_t *__restrict__ out)
 {
+    HHGT_WAVE_PRIO();
     __shared__ uint32_t sm[8];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
@@ -123,6 +126,7 @@ template <int B>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce_n(const uint32_t *__restrict__ in0, const uint32_t *__restrict__ in1,
                                                               uint64_t n, uint32_t *__restrict__ partial, uint32_t nb)
 {
+    HHGT_WAVE_PRIO();
     __shared__ uint32_t sm[8];
     const uint32_t *ins[2] = {in0, in1};
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_down_n(const uint32_t *__re
                                                             uint64_t n, const uint32_t *__restrict__ partial, uint32_t nb,
                                                             uint32_t *__restrict__ out0, uint32_t *__restrict__ out1)
 {
+    HHGT_WAVE_PRIO();
     __shared__ uint32_t sm[8];
     const uint32_t *ins[2] = {in0, in1};
     uint32_t *outs[2] = {out0, out1};

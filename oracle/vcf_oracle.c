@@ -21,6 +21,21 @@
  * (l == 1) trips assert(ploidy()==2) in the reference (parse_vcf.cpp:46) unless another sample of
  * the same record is diploid; this build defines the second allele as -9 and counts it.
  *
+ * Two more edges the restatement decides, both outside anything the reference's files pin:
+ *   * stop.  Stop() = pos0 + rlen (vcfpp.h:1124-1127), and htslib of the era the reference names (>= 1.15) takes rlen
+ *     from INFO/END when a record carries one.  This restatement (and the product: parse_vcf.py, hhgt_encode_text)
+ *     uses stop = start + len(REF) — identical for every record that passes isSNP unless it carries END=, which SNP
+ *     records of the reference's fixture and of 1000G-style files do not.  A kept SNP record with INFO/END would get
+ *     stop = END from the reference and start + 1 here.
+ *   * short data lines at cohort widths.  A data line with fewer sample columns than the header is a parse error in
+ *     htslib; this oracle decodes what is there and pads the rest with -9 (tests/test_gpu_encode.py).  The product
+ *     agrees for S < 760; for wider files its line index hops over the first 2 S + 1 bytes behind every line start
+ *     (csrc/index.hip), so a line shorter than that merges with its successor: if the merged line is KEPT the encoder
+ *     sees the inner newline and the call fails with HHGT_ERR_MALFORMED (tests/test_gpu_index_hop.py pins this); if the
+ *     short line is DROPPED by the region / isSNP filter, the record behind it is dropped with it, unreported
+ *     (HHGT_INDEX_HOP=0 restores the plain scan).  Malformed input either way; stated here because it is a
+ *     difference from this oracle.
+ *
  * PARITY UNPINNED (by the grading rule): the reference holds no output vectors for this path and its loader cannot
  * be compiled here (htslib absent).  What pins this file is tests/golden/ — vectors derived from the reference's own
  * INPUT fixture (tests/data/chr22.filtered.vcf.gz) by an independent pure-Python splitter

@@ -112,3 +112,21 @@ def test_short_line_in_mid_file_is_reported(ctx, S):
     t = b"\n".join(hdr + rec[:10] + [short] + rec[11:]) + b"\n"
     with pytest.raises(HhgtError, match="Error parsing VCF file"):
         gpu_encode(ctx, t, S, region="chr5")
+
+
+@pytest.mark.parametrize("S", [800, 2100])
+def test_line_with_empty_sample_columns_is_reported_not_decoded(ctx, S):
+    """The one place where the product differs from the oracle on text the oracle accepts: a kept record whose sample
+    columns are mostly EMPTY (tab tab tab ...) is shorter than 2 S + 17 bytes.  The oracle decodes the empty columns as
+    missing calls (-9); below 760 samples so does the product (tests/test_gpu_encode.py).  At cohort widths the hopping
+    index merges such a line with its successor and the call FAILS with HHGT_ERR_MALFORMED — flagged, never a silently
+    different matrix (oracle/vcf_oracle.c header)."""
+    hdr, rec = body_lines(shard(S, 40))
+    cols = rec[10].split(b"\t")
+    empty = b"\t".join(cols[:9 + 5] + [b""] * (S - 5))       # 5 calls, then S - 5 empty columns: ~S + 80 bytes
+    assert len(empty) < 2 * S + 17
+    t = b"\n".join(hdr + rec[:10] + [empty] + rec[11:]) + b"\n"
+    o = oracle.vcf_encode(t, S, region="chr5")               # the oracle takes it
+    assert o["n_kept"] == 40 and (o["G"][5:, 10] == -9).all()
+    with pytest.raises(HhgtError, match="Error parsing VCF file"):
+        gpu_encode(ctx, t, S, region="chr5")

@@ -17,17 +17,17 @@ cd $R
 timeout -k 10 400 python3 bench.py > $O/bench.log 2>&1
 grep "^{" $O/bench.log > $O/bench_line.json
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O -o $tag --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-legs --no-check > $O/rocprof_stdout.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O -o $tag --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-legs --no-check --no-other-configs > $O/rocprof_stdout.log 2>&1
 grep "^{" $O/rocprof_stdout.log > $O/bench_line_under_rocprof.json
-B="python3 $R/bench.py --variants 300000 --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-legs --no-check"
+B="python3 $R/bench.py --variants 300000 --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-legs --no-check --no-other-configs"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O -o f --output-format csv -- $B > $O/out_f.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O -o w --output-format csv -- $B > $O/out_w.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU \
   --kernel-include-regex k_lz4 -d $O -o sq --output-format csv -- $B > $O/out_sq.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU \
+  --kernel-include-regex k_encode_planes -d $O -o sqe --output-format csv -- $B > $O/out_sqe.log 2>&1
+# the config-4 leg (exception-aware bit-plane coder, variable-width path) under the kernel trace
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O -o c4 --output-format csv -- python3 $R/bench.py --only-config C4 > $O/c4_line.json 2> $O/c4.log
 cd $R
-for k in "--kind bgzf" "--kind bgzf --device-inflate" "--kind plain" "--kind memory"; do
-  n=$(echo $k | tr -d ' -' )
-  timeout -k 10 300 python3 tools/e2e_bench.py $k --chroms 1,2,3,4 --repeat 3 > $O/e2e_$n.log 2>&1
-  grep "^{" $O/e2e_$n.log > $O/e2e_$n.json
-done
+# (the end-to-end legs are part of the default bench line since round 3: every shard, first / steady pass)
 ls $O

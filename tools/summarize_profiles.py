@@ -49,7 +49,7 @@ out = {
     "variants_per_pass": VARIANTS,
 }
 # the "lz4" stage is two launches per shard: the bit-plane coder, then the byte-wise coder over the streams it marked
-for name, kerns in (("lz4", ("k_lz4_bitplanes", "k_lz4_blocks")), ("encode", ("k_encode_tiles",)), ("index", ("k_index_newlines", "k_index_hop")),
+for name, kerns in (("lz4", ("k_lz4_bitplanes", "k_lz4_blocks")), ("encode", ("k_encode_tiles", "k_encode_planes")), ("index", ("k_index_newlines", "k_index_hop")),
                     ("frame", ("k_frame_write",)), ("fixed", ("k_parse_fixed",))):
     kerns = [k for k in kerns if k in f]
     if not kerns:
@@ -63,7 +63,7 @@ shutil.copy(find("counter_collection.csv", "sq_"), f"profiles/{prefix}_pmc_lz4_s
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 grid = collections.Counter()
 for r in csv.DictReader(open(f"profiles/{prefix}_pmc_lz4_sq.csv")):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")   # with the template arguments: <depth, planes input, exception-aware>
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES":
         grid[k] += int(r["Grid_Size"])
@@ -77,4 +77,19 @@ print("\n".join(lines))
 for f_ in os.listdir(src):
     if f_.startswith("e2e_") and f_.endswith(".json") and os.path.getsize(os.path.join(src, f_)):
         shutil.copy(os.path.join(src, f_), f"profiles/{prefix}_{f_}")
+# round 3: SQ counters of the bit-plane encode kernel, the config-4 leg and its kernel stats
+try:
+    shutil.copy(find("counter_collection.csv", "sqe_"), f"profiles/{prefix}_pmc_encode_planes_sq.csv")
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f"profiles/{prefix}_pmc_encode_planes_sq.csv")):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    with open(f"profiles/{prefix}_pmc_encode_planes_sq.txt", "w") as fo:
+        for k in acc:
+            waves = acc[k].get("SQ_WAVES", 0) or 1
+            fo.write(f"{k}: per wave " + json.dumps({c: round(v / waves, 1) for c, v in sorted(acc[k].items())}) + "\n")
+    shutil.copy(find("kernel_stats.csv", "c4"), f"profiles/{prefix}_c4_kernel_stats.csv")
+    shutil.copy(os.path.join(src, "c4_line.json"), f"profiles/{prefix}_c4_line.json")
+except FileNotFoundError as e:
+    print("round-3 extras missing:", e)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
