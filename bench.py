@@ -739,9 +739,11 @@ def main():
     if dom == "lz4":
         # the contract's roofline is HBM or MFMA; this kernel is bound by neither
         sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_lz4_sq.txt")))
-        roof["limiter"] = ("vector-instruction issue and LDS round trips: ~1.9 k vector + 0.7 k scalar + 0.25 k LDS instructions "
-                           "per 4 KiB plane at 7 waves per SIMD (" + (os.path.basename(sq[-1]) if sq else "profiles/") +
-                           ", SQ counters from a separate --pmc pass); HBM at a sixth of its peak under this kernel")
+        roof["limiter"] = ("the length of a wave's dependent chain (~220 LDS instructions per plane, most of them round trips, between "
+                           "dependent vector instructions): ~1.7 k vector + 1.0 k scalar + 0.22 k LDS instructions per 4 KiB plane at 7 waves "
+                           "per SIMD (" + (os.path.basename(sq[-1]) if sq else "profiles/") + ", SQ counters from a separate --pmc pass); "
+                           "stage time follows occupancy (12.2 / 13.3 / 14.9 / 17.2 ms at 14 / 13 / 11 / 9 workgroups per CU), not the "
+                           "instruction count; HBM at a sixth of its peak under this kernel")
 
     out = {
         "metric": "variants/sec encode+compress, 3M-variant x 2.5k-sample VCF",
