@@ -300,7 +300,9 @@ def stream_file(ctx, path, region="", sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, bloc
     fs = FileStats()
     d = ctx.device
     device_inflate = _want_device_inflate(device_inflate)
-    if device_inflate and _is_bgzf_file(path):   # ("auto" in this single-file form: every BGZF file)
+    if device_inflate == "auto":   # this single-file form: every BGZF file, unless the caller's text blocks are too small for the device path
+        device_inflate = block_bytes is None or block_bytes >= (5 << 20)
+    if device_inflate and _is_bgzf_file(path):
         # one wave per member: a launch wants >= 10 k members (64 KiB of text each) to fill the chip, so the text
         # block is 1 GiB unless the file is smaller (measured: 64 MiB blocks 1.4 M variants/s, 1 GiB 4.0 M)
         rd = _DeviceBgzfBlocks(ctx, path, block_bytes)
