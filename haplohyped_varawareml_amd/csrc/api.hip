@@ -766,15 +766,13 @@ static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, P
     const uint64_t n_streams = n_chunks * nblocks * nwaves;
     TRY(c->lz_scratch.ensure((size_t)n_streams * slot));
     TRY(c->lz_csize.ensure((size_t)n_streams * 4));
-    TRY(c->lz_marked.ensure(((size_t)n_streams + 4) * 4));   // [0]: count, [1..]: queued blocks (streams >= blocks)
     TRY(c->fr_bsize.ensure((size_t)n_chunks * nblocks * 4));
     TRY(c->fr_csize.ensure(((size_t)n_chunks + 1) * 8));
     TRY(c->fr_flags.ensure((size_t)n_chunks * 4));
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
         TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), pg, n_chunks, chunk_nbytes, typesize,
-                              blocksize, c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel,
-                              c->lz_marked.as<uint32_t>() + 1, c->lz_marked.as<uint32_t>(), st));
+                              blocksize, c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel, st));
         t.stop();
     }
     {

@@ -226,11 +226,10 @@ size_t lz4_slot_bytes(int neblock);
 // d_planes != NULL: the chunks exist as bit planes (hhgt.h "Bit-plane form"); d_src then only supplies the bytes of calls
 // beyond 0 / 1 / missing and may be NULL
 int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
-                      uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st);
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel, hipStream_t st);
 // lz4bits.hip: typesize 2, 8 KiB blocks; streams it cannot code get csize = 0xFFFFFFFF
 int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
-                         uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st);
+                         int depth, hipStream_t st);
 // frame.hip
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
                  PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,

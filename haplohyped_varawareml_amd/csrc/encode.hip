@@ -482,21 +482,25 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
     }
 }
 
-// EDGE: the band of sample columns that holds the last sample (and lanes past it) reads with care; every other band
-// reads 16 bytes flat.  Two instantiations, two launches: the hot one does not carry the careful one's registers.
-template <bool EDGE>
-__global__ __launch_bounds__(64 * PT_NW, EDGE ? 2 : PT_WGS) void k_encode_planes(const uint8_t *__restrict__ text, uint64_t n,
+// The band of sample columns that holds the last sample (and lanes past it) reads with care (EDGE); every other band reads
+// 16 bytes flat.  One launch, a workgroup-uniform branch: since the medium path is a rolled loop both bodies fit the same
+// 125 registers, and the last band's tiles fill the tail of the grid instead of being an under-filled launch of their own
+// (round 3 first split them: 1.2 of 7.8 ms per step).
+__global__ __launch_bounds__(64 * PT_NW, PT_WGS) void k_encode_planes(const uint8_t *__restrict__ text, uint64_t n,
                                                           const uint32_t *__restrict__ k_soff, const uint32_t *__restrict__ k_meta,
                                                           const uint64_t *__restrict__ d_cursor, LayoutDev lay,
                                                           uint8_t *__restrict__ P, int8_t *__restrict__ G,
                                                           uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
-                                                          DevCounters *cnt, uint32_t band0)
+                                                          DevCounters *cnt)
 {
     HHGT_WAVE_PRIO();
     __shared__ __attribute__((aligned(16))) uint32_t img[1024 * PT_ROWDW];   // 32 KiB
     const uint64_t v_base = *d_cursor;
     const uint32_t n_kept = (uint32_t)cnt->n_kept;
-    encode_planes_tile<EDGE>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, band0);
+    if (blockIdx.y + 1u == gridDim.y)
+        encode_planes_tile<true>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, 0u);
+    else
+        encode_planes_tile<false>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, 0u);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -796,11 +800,8 @@ int launch_encode_planes(const uint8_t *d_text, uint64_t n, const uint32_t *k_so
     const uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
     // the append position is only known on the device: one tile more than the lines need covers any phase
     const uint64_t tiles_v = ((uint64_t)(PT_V - 1) + (uint64_t)n_lines_bound + (PT_V - 1)) / PT_V;
-    if (tiles_s > 1)
-        hipLaunchKernelGGL(k_encode_planes<false>, dim3((uint32_t)tiles_v, tiles_s - 1), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta,
-                           d_cursor, lay, d_P, d_G, redo_list, redo_flag, d_cnt, 0u);
-    hipLaunchKernelGGL(k_encode_planes<true>, dim3((uint32_t)tiles_v, 1), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta, d_cursor,
-                       lay, d_P, d_G, redo_list, redo_flag, d_cnt, tiles_s - 1);
+    hipLaunchKernelGGL(k_encode_planes, dim3((uint32_t)tiles_v, tiles_s), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta, d_cursor, lay,
+                       d_P, d_G, redo_list, redo_flag, d_cnt);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

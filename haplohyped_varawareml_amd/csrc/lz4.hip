@@ -651,26 +651,30 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
                                                      uint64_t chunk_nbytes, uint32_t typesize, uint32_t blocksize,
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
-                                                     uint32_t *__restrict__ csize, const uint32_t *__restrict__ marked,
-                                                     const uint32_t *__restrict__ n_marked, const uint8_t *__restrict__ planes,
+                                                     uint32_t *__restrict__ csize, uint32_t n_total, const uint8_t *__restrict__ planes,
                                                      PlanesGeom pg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
-    // algo bit 8: list mode — only the blocks the bit-plane encoder (lz4bits.hip) queued, and of those only the streams it
-    // left marked (csize == 0xFFFFFFFF), are coded; the (small, fixed) grid walks the list
+    // algo bit 8: scan mode — only the streams the bit-plane encoders (lz4bits.hip) left marked (csize == 0xFFFFFFFF) are
+    // coded: the (small, fixed) grid scans the stream sizes, 64 blocks per load, and works on the blocks that still hold one
     const bool only_marked = (algo & 0x100u) != 0u;
-    const uint32_t n_list = only_marked ? *n_marked : 1u;
-    for (uint32_t it = blockIdx.x; it < (only_marked ? n_list : blockIdx.x + 1u); it += gridDim.x) {
-    const uint32_t bid = only_marked ? marked[it] : blockIdx.x;
+    for (uint32_t b0 = only_marked ? blockIdx.x * 64u : blockIdx.x; b0 < (only_marked ? n_total : blockIdx.x + 1u);
+         b0 += only_marked ? gridDim.x * 64u : 1u) {
+    unsigned long long todo = 1ull;
+    if (only_marked) {   // every wave of the workgroup reads the same sizes and gets the same mask
+        const uint32_t bb = b0 + (threadIdx.x & 63u);
+        bool any = false;
+        if (bb < n_total)
+            for (uint32_t j = 0; j < nwaves; ++j) any = any || csize[(uint64_t)bb * nwaves + j] == 0xFFFFFFFFu;
+        todo = __builtin_amdgcn_ballot_w64(any);
+    }
+    while (todo != 0ull) {   // (workgroup-uniform)
+    const uint32_t bid = only_marked ? b0 + (uint32_t)__builtin_ctzll(todo) : b0;
+    todo &= todo - 1ull;
     // wave index through readfirstlane: everything derived from it (stream base, output slot) stays in SGPRs,
     // so the byte stores below use the SGPR-base + 32-bit-offset addressing form
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    if (only_marked) {   // a listed block whose streams have all been coded since (the exception-aware bit-plane coder): nothing to load
-        bool any = false;
-        for (uint32_t j = 0; j < nwaves; ++j) any = any || csize[(uint64_t)bid * nwaves + j] == 0xFFFFFFFFu;
-        if (!any) continue;   // (workgroup-uniform)
-    }
     const uint64_t chunk = bid / nblocks;
     const uint32_t b = bid - (uint32_t)(chunk * nblocks);
     const uint64_t boff = (uint64_t)b * blocksize;
@@ -761,13 +765,13 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
     } else if (lane == 0) {
         csize[(uint64_t)bid * nwaves + wave] = 0u;
     }
-    if (only_marked) __syncthreads();   // the next block of the list reuses the LDS
+    if (only_marked) __syncthreads();   // the next marked block reuses the LDS
+    }
     }
 }
 
 int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel,
-                      uint32_t *d_marked, uint32_t *d_n_marked, hipStream_t st)
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel, hipStream_t st)
 {
     if (d_planes && (typesize != 2 || blocksize != 8192 || chunk_nbytes % 8192 || (reinterpret_cast<uintptr_t>(d_planes) & 15u))) {
         hhgt_set_error("lz4: bit planes stand for typesize 2, 8 KiB blocks, chunks of whole blocks, 16-byte aligned");
@@ -779,13 +783,13 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     // HHGT_LZ4_BITPLANES=0 keeps everything on the byte-wise encoder.
     static const bool bp_env = !(getenv("HHGT_LZ4_BITPLANES") && atoi(getenv("HHGT_LZ4_BITPLANES")) == 0);
     const bool bitplanes = bp_env && typesize == 2 && blocksize == 8192 && chunk_nbytes % 8192 == 0 &&
-                           (d_planes || (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0) && slot_bytes >= 4128 && d_marked && d_n_marked;
+                           (d_planes || (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0) && slot_bytes >= 4128;
     if (bitplanes) {
         // effort: candidates tried per one along the hash chain (clevel 1-2: none, offset-1 runs only)
         static const int depth_env = getenv("HHGT_LZ4_DEPTH") ? atoi(getenv("HHGT_LZ4_DEPTH")) : -1;
         const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 16);
         const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, pg, n_chunks * (chunk_nbytes / 8192), d_scratch,
-                                            slot_bytes, d_csize, d_marked, d_n_marked, depth, st);
+                                            slot_bytes, d_csize, depth, st);
         if (rc != HHGT_OK) return rc;
     }
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
@@ -840,8 +844,8 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     const uint32_t algo = algo_env | (bitplanes ? 0x100u : 0u);
     uint64_t grid = n_chunks * nblocks;
     if (grid == 0) return HHGT_OK;
-    // list mode: a fixed grid (enough workgroups to fill the chip) walks the queued blocks
-    if (bitplanes && grid > 256u * 14u) grid = 256u * 14u;
+    // scan mode: a fixed grid (enough workgroups to fill the chip) scans the stream sizes, 64 blocks per workgroup and step
+    if (bitplanes) grid = (grid + 63) / 64 < 256u * 14u ? (grid + 63) / 64 : 256u * 14u;
     if (grid > 0x7fffffffull) {
         hhgt_set_error("lz4: too many blocks");
         return HHGT_ERR_ARG;
@@ -859,7 +863,7 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
 #define LZ_LAUNCH2(MWV, ALG, PL)                                                                                      \
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG, PL>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks, \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
-                       (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked, d_planes, pg)
+                       (uint64_t)slot_bytes, d_csize, (uint32_t)(n_chunks * nblocks), d_planes, pg)
 #define LZ_LAUNCH(MWV, ALG) LZ_LAUNCH2(MWV, ALG, false)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)

@@ -265,33 +265,38 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
 // line, so the blocks are dealt to the workgroups in an XCD-aware order: of 64 consecutive workgroups the eight that land
 // on one XCD (round robin) take eight consecutive blocks — one L2 fetches each line once.
 // EXC (with PLANES): the exception-aware instantiation — planes whose bytes are 0, 1 or 0xF7 (missing calls; config 4).
-// It walks the list of blocks the plain instantiation queued (marked / n_marked) on a fixed grid and codes the streams
-// that one left marked; the bit map is the map of NONZERO bytes, a second map says which of them are 0xF7, every one
+// On a fixed grid every wave scans the stream sizes of its plane, 64 blocks per load, and codes the streams the plain
+// instantiation left marked (csize = 0xFFFFFFFF; a list of marked blocks built by atomic adds on one counter cost more than
+// the coding itself when every plane is marked: 6 ms for config 4's 537 k blocks); the bit map is the map of NONZERO bytes, a second map says which of them are 0xF7, every one
 // carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
 // Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
 template <int DEPTH, bool PLANES, bool EXC>
 __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
-                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
-                                                          uint32_t *__restrict__ marked, uint32_t *__restrict__ n_marked)
+                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize)
 {
     static_assert(!EXC || PLANES, "the exception-aware coder reads bit planes");
     constexpr bool CHAIN = DEPTH > 1;
     __shared__ BpLds<CHAIN, EXC> lds[2];
     __shared__ uint32_t nonbin[2][2];
-    __shared__ uint32_t queued;   // the block goes into the byte-wise encoder's list once, whichever wave asks first
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    // EXC: `return` inside the body means "next block of the list" (the two waves of a workgroup are independent there)
+    // EXC: `return` inside the body means "next marked block" (the two waves of a workgroup are independent there)
 #define BP_DONE()               \
     do {                        \
         if (EXC) goto bp_next;  \
         else return;            \
     } while (0)
-    const uint32_t n_items = EXC ? *n_marked : 1u;
-    for (uint32_t item = EXC ? blockIdx.x : 0u; item < n_items; item += EXC ? gridDim.x : 1u) {
+    for (uint32_t b0 = EXC ? blockIdx.x * 64u : 0u; b0 < (EXC ? n_blocks : 1u); b0 += EXC ? gridDim.x * 64u : 1u) {
+    unsigned long long todo = 1ull;
+    if (EXC) {   // which of the 64 blocks from b0 on still have this wave's stream marked
+        const uint32_t bb = b0 + lane;
+        todo = __builtin_amdgcn_ballot_w64(bb < n_blocks && csize[(uint64_t)bb * 2u + wave] == 0xFFFFFFFFu);
+    }
+    while (todo != 0ull) {   // (wave-uniform)
     {
-    const uint32_t bid = EXC ? marked[item] : PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
+    const uint32_t bid = EXC ? b0 + (uint32_t)__builtin_ctzll(todo)
+                             : PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
+    todo &= todo - 1ull;
     if (PLANES && !EXC && bid >= n_blocks) return;   // (the grid is rounded up to whole groups of 64)
-    if (EXC && csize[(uint64_t)bid * 2u + wave] != 0xFFFFFFFFu) BP_DONE();   // coded by the plain instantiation
     uint32_t xlo = 0, xhi = 0;   // EXC: the lane's 64 positions of the missing-call map
     uint32_t wlo, whi;
     bool nonbinary;
@@ -318,8 +323,6 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
             if (lane < 24u) lds[wave].cls[lane] = 0u;
         } else {
             nonbinary = __builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) != 0ull;
-            if (threadIdx.x == 0) queued = 0u;
-            __syncthreads();   // (for `queued` only: each wave works on what it loaded itself)
         }
     } else {
     const uint8_t *blk = src + (uint64_t)bid * 8192u;
@@ -362,7 +365,6 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
             nonbin[wave][1] = b1 != 0ull;
         }
         if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
-        if (threadIdx.x == 0) queued = 0u;
     }
     __syncthreads();
     wlo = lds[wave].bm[2u * lane];
@@ -397,11 +399,8 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
     const uint32_t incl = bp_scan_sum(cnt, lane);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (nonbinary || m > BP_MAXONES) {
-        if (EXC) BP_DONE();   // stays marked: the byte-wise kernel walks the same list next
-        if (lane == 0) {   // left to the next coder: mark the stream, queue its block (once: two workgroups on one
-            csize[sidx] = 0xFFFFFFFFu;   // block would write two different valid encodings into the same slot)
-            if (atomicExch(&queued, 1u) == 0u) marked[atomicAdd(n_marked, 1u)] = bid;
-        }
+        if (EXC) BP_DONE();   // stays marked: the byte-wise kernel scans for it next
+        if (lane == 0) csize[sidx] = 0xFFFFFFFFu;   // left to the next coder
         return;
     }
     BP_MARK("scan_done");
@@ -706,35 +705,35 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
     }
 bp_next:;
     }
+    }
 #undef BP_DONE
 }
 
 int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
-                         uint32_t *d_marked, uint32_t *d_n_marked, int depth, hipStream_t st)
+                         int depth, hipStream_t st)
 {
     if (n_blocks == 0) return HHGT_OK;
     if (n_blocks > 0x7fffffffull) {
         hhgt_set_error("lz4: too many blocks");
         return HHGT_ERR_ARG;
     }
-    HIP_TRY(hipMemsetAsync(d_n_marked, 0, 4, st));
     // development: extra (unused) dynamic LDS per workgroup caps how many workgroups a CU holds, which leaves LDS and
     // wave slots to a kernel running beside this one on another stream
     static const int lds_pad = getenv("HHGT_LZ4_LDS_PAD") ? atoi(getenv("HHGT_LZ4_LDS_PAD")) : 0;
-    // the exception-aware instantiation walks the list the plain one queued, on a grid that fills the chip (HHGT_LZ4_EXC=0:
-    // every marked stream goes to the byte-wise kernel, as before round 3)
+    // the exception-aware instantiation scans for the streams the plain one marked, on a grid that fills the chip
+    // (HHGT_LZ4_EXC=0: every marked stream goes to the byte-wise kernel, as before round 3)
     static const bool exc_env = !(getenv("HHGT_LZ4_EXC") && atoi(getenv("HHGT_LZ4_EXC")) == 0);
-    const uint32_t exc_grid = (uint32_t)(n_blocks < 256u * 12u ? n_blocks : 256u * 12u);
+    const uint32_t exc_grid = (uint32_t)((n_blocks + 63) / 64 < 256u * 12u ? (n_blocks + 63) / 64 : 256u * 12u);
 #define BP_LAUNCH2(D, PL)                                                                                                   \
     hipLaunchKernelGGL((k_lz4_bitplanes<D, PL, false>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
-                       d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked)
+                       d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize)
 #define BP_LAUNCH(D)                                                                                                        \
     do {                                                                                                                    \
         if (planes) {                                                                                                       \
             BP_LAUNCH2(D, true);                                                                                            \
             if (exc_env)                                                                                                    \
                 hipLaunchKernelGGL((k_lz4_bitplanes<D, true, true>), dim3(exc_grid), dim3(128), 0, st, d_src, pg, (uint32_t)n_blocks, d_scratch, \
-                                   (uint64_t)slot_bytes, d_csize, d_marked, d_n_marked);                                    \
+                                   (uint64_t)slot_bytes, d_csize);                                                          \
         } else                                                                                                              \
             BP_LAUNCH2(D, false);                                                                                           \
     } while (0)
