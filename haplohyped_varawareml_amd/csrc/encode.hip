@@ -565,7 +565,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
     // each wave stages the 1 KiB piece it is ranking (plus a halo) in LDS: the per-field byte walk then reads LDS
     // instead of issuing one global load per character
     __shared__ __attribute__((aligned(16))) uint8_t sbuf[4][1024 + GEN_HALO];
-    uint8_t *buf = sbuf[threadIdx.x >> 6];
+    // (the staged piece is always reached as sbuf[wq][...]: through a pointer variable the reader lambda below lost the LDS
+    // address space and every character was a flat_load — 915 global-load instructions per line, 520 us per line)
+    const uint32_t wq = threadIdx.x >> 6;
+#define buf (sbuf[wq])
     uint32_t haploid = 0, malformed = 0;
     for (uint32_t idx = wave; idx < n_redo; idx += n_waves) {
         const uint32_t k = redo_list[idx];
@@ -575,6 +578,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         uint64_t vcol = v / lay.Vc;
         const uint64_t vin = v - vcol * lay.Vc;
         if (lay.ring) vcol %= lay.ring;
+        // bit-plane form: where this line's bit lives in every sample's piece of the tile (wave-uniform)
+        const uint64_t kstride = (uint64_t)pgeom.S_pad * 8ull;   // dwords between the kind-planes of a tile
+        uint8_t *pline = PLANES ? P + planes_piece(pgeom, vcol, (uint32_t)(vin / PL_TILE), 0u, 0u) + (((uint32_t)(vin % PL_TILE) >> 5) << 2) : nullptr;
+        const uint32_t pmask = 1u << ((uint32_t)(vin % PL_TILE) & 31u);
         const uint32_t rs = soff - 1u;  // the 9th tab: every sample field is preceded by a tab in [rs, lend)
         uint32_t tabs_before = 0, nl_inside = 0;
         for (uint32_t base = rs; base < lend; base += 1024u) {
@@ -615,9 +622,14 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 }
             }
             const uint32_t avail = lend - base < 1024u + GEN_HALO ? lend - base : 1024u + GEN_HALO;
+            // the staged piece through a pointer that CARRIES the LDS address space: as a generic pointer (or as one arm of a
+            // select against the global text) every character the reader below fetches became a flat_load
+            typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+            lds_u8 *lbuf = (lds_u8 *)(uintptr_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)sbuf[wq];
             auto rd = [&](uint32_t p) -> uint32_t {
                 const uint32_t o = p - base;
-                return o < avail ? (uint32_t)buf[o] : (uint32_t)text[p];  // beyond the halo: rare long sub-fields
+                if (o < avail) return (uint32_t)lbuf[o];
+                return (uint32_t)text[p];  // beyond the halo: rare long sub-fields
             };
             uint32_t c = __popc(m), inc = c;
 #pragma unroll
@@ -642,36 +654,59 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                     }
                 }
                 uint32_t na = 1, hv = 0xF7F7u;
-                if (!missing) {
+                bool done = false;
+                if (gtidx == 0u && p - base + 8u <= avail) {
+                    // the common column: GT comes first and reads "a|b" / "a/b" with a, b in {0, 1, .}, closed by ':', a tab or
+                    // the line end.  Four bytes from the staged piece (two aligned dwords, one funnel shift), the same
+                    // branch-free classification as the tile kernel's second level.
+                    const uint32_t o = p - base;
+                    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(sbuf[wq]);
+                    uint32_t x = __builtin_amdgcn_alignbyte(w32[(o >> 2) + 1u], w32[o >> 2], o & 3u);
+                    if (p + 3u >= lend) x = (x & 0x00FFFFFFu) | 0x09000000u;   // the line (and the text) ends behind the call
+                    const uint32_t y = x ^ 0x09307C30u;
+                    const uint32_t yt = y >> 24;                                    // terminator: '\t', '\n' or ':'
+                    const uint32_t t4 = y >> 4;
+                    const uint32_t e2 = t4 & 0x00010001u, o2 = (y | t4) & 0x00010001u;
+                    const uint32_t want = __umul24(e2, 30u) | (y & 0x00010001u & ~e2);
+                    const uint32_t z = y & 0x0000FF00u, zz = z ^ 0x00005300u;
+                    const uint32_t off = ((y & 0x00FF00FFu) ^ want) | (z < zz ? z : zz);
+                    if (off == 0u && (yt == 0u || yt == 0x03u || yt == 0x33u) && p + 3u <= lend) {
+                        const uint32_t h0 = (e2 & 1u) ? 0xF7u : (o2 & 1u), h1 = (e2 >> 16) ? 0xF7u : (o2 >> 16);
+                        hv = h0 | (h1 << 8);
+                        na = 2u;
+                        done = true;
+                    }
+                }
+                if (!done && !missing) {
                     // the sub-field ends at ':' or at the column's tab; both stop the GT rule
                     hv = parse_gt_bytes(rd, p, lend, &na);
                 }
                 if (na == 1u) ++haploid;
-                const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
-                const uint32_t sin = s - scol * lay.Sc;
-                const uint64_t goff = (((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull;
+                auto g_off = [&]() -> uint64_t {   // the call's place in the int8 matrix (64-bit multiplies: only where it is needed)
+                    const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
+                    const uint32_t sin = s - scol * lay.Sc;
+                    return (((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull;
+                };
                 if (!PLANES) {
-                    *reinterpret_cast<uint16_t *>(G + goff) = (uint16_t)hv;
+                    *reinterpret_cast<uint16_t *>(G + g_off()) = (uint16_t)hv;
                 } else {
-                    const uint32_t bit = (uint32_t)(vin % PL_TILE);
-                    const uint64_t kstride = (uint64_t)pgeom.S_pad * 8ull;   // dwords between the kind-planes of a tile
-                    uint32_t *pw = reinterpret_cast<uint32_t *>(P + planes_piece(pgeom, vcol, (uint32_t)(vin / PL_TILE), 0u, s)) + (bit >> 5);
-                    const uint32_t mk = 1u << (bit & 31u);
+                    // (pline: the line's tile and bit are the same for every sample — wave-uniform, computed once per line)
+                    uint32_t *pw = reinterpret_cast<uint32_t *>(pline + (uint64_t)s * 32ull);
                     const uint32_t h0 = hv & 0xFFu, h1 = (hv >> 8) & 0xFFu;
-                    if (h0 == 1u || h0 == 0xF7u) atomicOr(pw, mk);
-                    if (h1 == 1u || h1 == 0xF7u) atomicOr(pw + kstride, mk);
+                    if (h0 == 1u || h0 == 0xF7u) atomicOr(pw, pmask);
+                    if (h1 == 1u || h1 == 0xF7u) atomicOr(pw + kstride, pmask);
                     if (h0 > 1u) {
-                        atomicOr(pw + 2ull * kstride, mk);
+                        atomicOr(pw + 2ull * kstride, pmask);
                         if (h0 != 0xF7u) {
                             atomicAdd(&cnt->n_other, 1ull);
-                            if (G) G[goff] = (int8_t)h0;
+                            if (G) G[g_off()] = (int8_t)h0;
                         }
                     }
                     if (h1 > 1u) {
-                        atomicOr(pw + 3ull * kstride, mk);
+                        atomicOr(pw + 3ull * kstride, pmask);
                         if (h1 != 0xF7u) {
                             atomicAdd(&cnt->n_other, 1ull);
-                            if (G) G[goff + 1ull] = (int8_t)h1;
+                            if (G) G[g_off() + 1ull] = (int8_t)h1;
                         }
                     }
                 }
@@ -691,6 +726,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         if (malformed) atomicAdd(&cnt->n_malformed, (unsigned long long)malformed);
     }
 }
+#undef buf
 
 // -------------------------------------------------------------------------------------------------
 // zero columns [c0, c1) (variant index inside the chunk column) of rows [r0, r1) (sample index inside
