@@ -210,8 +210,12 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 #define PT_NW 4            // waves per workgroup
 #endif
 #define PT_LW (PT_V / PT_NW)   // lines per wave
+#ifndef PT_ALIGNED
+#define PT_ALIGNED 0       // 0: one byte-aligned 16-byte load per lane.  1 (measured, not faster: 0.61 against 0.56 ms per chr1-sized
+#endif                     //    shard): every lane loads the two ALIGNED chunks that hold its 16 bytes (the second is its neighbour's
+                           //    first: an L1 hit) and funnel-shifts when the group is packed
 #ifndef PT_G
-#define PT_G 8             // lines per load group
+#define PT_G (PT_ALIGNED ? 4 : 8)   // lines per load group (aligned form: two registers quads per line)
 #endif
 #ifndef PT_DB
 #define PT_DB 1            // the next group's loads are issued before a group is packed
@@ -223,8 +227,40 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 
 struct PlGroup {
     uint4 raw[PT_G];
+#if PT_ALIGNED
+    uint4 hi[PT_G];    // the aligned chunk behind raw[j]; the line's 16 bytes start at byte mis[j] of (raw[j], hi[j])
+    uint32_t mis[PT_G];
+#endif
     uint32_t lvalid;   // bit j: line j of the group is a kept fixed-width line (wave-uniform)
 };
+
+// bytes [m, m + 16) of the 32 bytes (lo, hi); m is wave-uniform
+__device__ __forceinline__ uint4 pl_funnel(const uint4 lo, const uint4 hi, const uint32_t m)
+{
+    if (m == 0u) return lo;
+    const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const uint32_t sh = m & 3u;
+    uint32_t o[4];
+    switch (m >> 2) {   // (wave-uniform)
+    case 0:
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+        break;
+    case 1:
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 2], d[i + 1], sh);
+        break;
+    case 2:
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 3], d[i + 2], sh);
+        break;
+    default:
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 4], d[i + 3], sh);
+        break;
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // the line table of 32 lines at once: lane j holds soff / meta of line kb + j (meta = 0 beyond the batch), so that a
 // load group needs no scalar loads (the first version paid two dependent s_load round trips in front of every line)
@@ -252,9 +288,10 @@ __device__ __forceinline__ uint4 pl_load_line(const uint8_t *__restrict__ text, 
     const uint64_t off = (uint64_t)soff + 4ull * ls;
     if (!EDGE) {
         // Every lane owns four samples in front of the line's last one: the 16 bytes lie inside the line.  (They start
-        // wherever the line's sample columns start; a wave-load whose lanes are not dword-aligned runs at ~80 % of an aligned
-        // one — tools/micro/strided_read.hip.  Loading aligned chunks and funnel-shifting with the neighbour lane's data was
-        // tried: correct, and no faster — the 65th chunk needs its own load per line, which costs what the alignment wins.)
+        // wherever the line's sample columns start; in isolation a wave-load whose lanes are not dword-aligned runs at ~80 % of
+        // an aligned one — tools/micro/strided_read.hip.  Two aligned forms were built and measured in round 3, both correct,
+        // neither faster: aligned chunks + the neighbour lane's data by wavefront shift (the 65th chunk needs its own load per
+        // line), and two aligned loads per lane with a deferred funnel shift (PT_ALIGNED=1).)
         u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
         v = make_uint4(t.x, t.y, t.z, t.w);
     } else {
@@ -297,11 +334,38 @@ __device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__rest
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)stp.meta, j0 + j);
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)stp.soff, j0 + j);
         uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
+#if PT_ALIGNED
+        uint4 h = v;
+        uint32_t m = 0;
+#endif
         if (meta & LF_FAST) {   // (wave-uniform)
             lv |= 1u << j;
+#if PT_ALIGNED
+            // Not the band of the last sample: behind this band's 1024 bytes the line goes on.  The 16 bytes of a lane start
+            // wherever the line's sample columns start, and a wave-load whose lanes are not dword-aligned runs at ~80 %
+            // (tools/micro/strided_read.hip): every lane loads the aligned chunk that holds its first byte and the one
+            // behind it (its neighbour's first: an L1 hit); the misalignment is the same for all lanes; pl_funnel picks the
+            // bytes when the group is packed, so all loads of a group are in flight before the first is used.
+            const uint64_t off = (uint64_t)soff + 4ull * ls;
+            m = EDGE ? 0u : (soff & 15u);   // (text is 16-byte aligned and 4 * ls a multiple of 16: the same m in every lane)
+            if (!EDGE && m != 0u && (uint64_t)soff + 4ull * (ls & ~255u) - m + 1040ull <= n) {
+                const u32x4_al *pa = reinterpret_cast<const u32x4_al *>(text + (off - m));
+                const u32x4_al c0 = __builtin_nontemporal_load(pa), c1 = __builtin_nontemporal_load(pa + 1);
+                v = make_uint4(c0.x, c0.y, c0.z, c0.w);
+                h = make_uint4(c1.x, c1.y, c1.z, c1.w);
+            } else {
+                m = 0u;
+                v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
+            }
+#else
             v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
+#endif
         }
         gr.raw[j] = v;
+#if PT_ALIGNED
+        gr.hi[j] = h;
+        gr.mis[j] = m;
+#endif
     }
     gr.lvalid = lv;
 }
@@ -324,7 +388,11 @@ __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, u
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, bad = 0;
 #pragma unroll
     for (int j = 0; j < PT_G; ++j) {
+#if PT_ALIGNED
+        const uint4 x = pl_funnel(gr.raw[j], gr.hi[j], gr.mis[j]);
+#else
         const uint4 x = gr.raw[j];
+#endif
         a0 |= (x.x & 0x00010001u) << (sh + j);
         a1 |= (x.y & 0x00010001u) << (sh + j);
         a2 |= (x.z & 0x00010001u) << (sh + j);
