@@ -38,6 +38,8 @@ for line in open(out):
     kind = "valu" if op.startswith("v_") else "salu" if op.startswith("s_") else "lds" if op.startswith("ds_") else \
         "vmem" if op.startswith(("global_", "flat_", "buffer_", "scratch_")) else "other"
     cnt.setdefault(sec, collections.Counter())[kind] += 1
+    if op == "s_waitcnt" and "lgkmcnt" in t:
+        cnt[sec]["lgkm_wait"] += 1          # a wait on LDS / scalar-memory results: one link of the wave's dependent chain
 print(f"k_lz4_bitplanes<{depth}>: instructions in the listing after each marker")
 for k, c in cnt.items():
-    print(f"  {k:12s} valu {c['valu']:5d}  salu {c['salu']:5d}  lds {c['lds']:4d}  vmem {c['vmem']:4d}")
+    print(f"  {k:12s} valu {c['valu']:5d}  salu {c['salu']:5d}  lds {c['lds']:4d}  vmem {c['vmem']:4d}  waits on lds {c['lgkm_wait']:3d}")
