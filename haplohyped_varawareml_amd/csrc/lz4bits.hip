@@ -18,13 +18,17 @@
 //   * match lengths come from comparing GAPS between ones, not bytes: equal gaps, then one plus the shorter of the
 //     first unequal pair.  The gaps also exist as BYTES (clipped to 255), so a candidate is judged by one unaligned
 //     4-byte fetch, an xor and a count-trailing-zeros (three gaps + the open one); the longest agreement along the chain
-//     wins (picking by length packs tighter than picking by the local saving: the parse is greedy) and only the winner
-//     is worked out exactly from the positions, extended past the third gap where it still agrees, pulled back over up
-//     to 8 literal zeros in front, and priced;
+//     wins — the zeros the two have in common IN FRONT count as well: a match is pulled back over them (up to 64) —
+//     (picking by length packs tighter than picking by the local saving: the parse is greedy) and only the winner
+//     is worked out exactly from the positions, extended past the third gap where it still agrees, pulled back over
+//     the zeros in front, and priced;
 //   * every one decides locally between "match" and "literal" by cost (3 bytes per sequence against the literals and
 //     runs it replaces) and thereby where the next coded one is: the greedy parse is a linked list nxt(j), followed
 //     inside a window by pointer doubling (6 rounds), not by a serial loop;
-//   * behind whatever a coded one ends with, the zeros up to the next one go out as an offset-1 run;
+//   * behind whatever a coded one ends with, the zeros up to the next one go out as an offset-1 run — if there are
+//     four that the NEXT coded one's match does not pull back over anyway (decided at layout time, where the next
+//     coded one is the neighbouring queue entry; round 3: run rule and an 8-zero pull-back that knew nothing of
+//     each other packed 8 % looser with the same candidates);
 //   * every coded one lays out and writes its (at most two) sequences itself, literals generated from the bit map.
 //
 // tools/sim/gapenc_ref.c states the same algorithm on the CPU, decision for decision; the kernel's streams are
@@ -46,8 +50,9 @@
 #define BP_QCAP 100     // queued coded ones a wave can hold (a window adds at most 64 to fewer than 64)
 #define BP_HLOG 6
 #define BP_GAPCLIP 40
-#define BP_MINM 6
-#define BP_BACK 8
+#define BP_MINM 6     // total length a hash match must have
+#define BP_TMIN 4     // zeros an offset-1 run must cover to be worth its 3 bytes
+#define BP_BACK 64    // zeros in front of the one a match is pulled back over (round 2: 8)
 #define BP_STEPS 16   // exact extension of the chosen candidate
 #define BP_PICK 3     // full gaps the pick looks at (one dword of gap bytes)
 #ifdef BP_MARKS   // development: section markers in the ISA listing (hipcc -S -DBP_MARKS), tools/isa_sections.py counts per section
@@ -73,7 +78,8 @@ template <bool CHAIN, bool EXC> struct BpLds {
 };
 
 // a queued coded one: what its sequences need that does not depend on the sequences in front of it
-//   x: E (13 bits) | msr = q - nb (13) << 13 | onM << 26 | onT << 27 | (rs - E) << 28        (E: end of what the one codes)
+//   x: E (13 bits) | msr = q - nb (13) << 13 | onM << 26 | onT << 27 | (rs - E) << 28        (E: end of what the one codes;
+//      onT: the run is long enough — whether it is emitted is decided against the next entry, bp_emit_batch)
 //   y: re (13 bits) | off << 13                                                                (re: start of the next coded one)
 __device__ __forceinline__ uint2 bp_entry(uint32_t E, uint32_t msr, bool onM, bool onT, uint32_t rs, uint32_t re, uint32_t off)
 {
@@ -207,22 +213,39 @@ __device__ __forceinline__ void bp_flush(const uint8_t *stage, uint8_t *__restri
 }
 
 #define BP_FENCE() asm volatile("" ::: "memory")
-// layout + emission of the first n (<= 64) queued coded ones, one per lane, in stream order.  The end of a coded one's
-// last sequence is where the next one's literals start (pe): the neighbouring lane's value, no scan.
+// layout + emission of the first n (<= 64) of the qn queued coded ones, one per lane, in stream order (n < qn unless the
+// stream ends with entry n - 1: every entry sees its successor).  The end of a coded one's last sequence is where the
+// next one's literals start (pe): the neighbouring lane's value, no scan.
 struct BpOut {
     uint32_t prev_end, gop, sop;   // end of the last sequence; bytes written to global / staged
 };   // (by value: a reference across the "memory" fences would pin the counters to scratch memory)
 
 template <bool EXC, typename LDS>
-__device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8_t *__restrict__ out, uint32_t n, BpOut st, uint32_t lane)
+__device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8_t *__restrict__ out, uint32_t n, uint32_t qn, BpOut st, uint32_t lane)
 {
     const uint32_t *xm = S.xm;
     uint32_t prev_end = st.prev_end, gop = st.gop, sop = st.sop;
     const bool have = lane < n;
     const uint2 en = have ? S.queue[lane] : make_uint2(0u, 0u);
     const uint32_t E = en.x & 0x1FFFu, msr = (en.x >> 13) & 0x1FFFu, rs = E + (en.x >> 28), re = en.y & 0x1FFFu, off = en.y >> 13;
-    const bool onM = (en.x >> 26) & 1u, onT = (en.x >> 27) & 1u;
-    const uint32_t F = onT ? re : E;                                   // end of this one's last sequence
+    const bool onM = (en.x >> 26) & 1u;
+    bool onT = (en.x >> 27) & 1u;
+    {   // the run is dropped when the next coded one's match starts so far in front of its one that fewer than BP_TMIN
+        // zeros are left to the run (the next coded one with a match IS the next entry: msr <= re says so)
+        const uint32_t nx = lane + 1u < qn ? S.queue[lane + 1u].x : 0u;
+        const uint32_t nmsr = (nx >> 13) & 0x1FFFu;
+        const bool nM = (nx >> 26) & 1u;
+        uint32_t nbk = nM && nmsr <= re ? re - nmsr : 0u;
+        const uint32_t zt = re - rs;
+        nbk = nbk < zt ? nbk : zt;
+        onT = onT && zt - nbk >= BP_TMIN;
+    }
+    // end of this one's last sequence.  An entry whose run was dropped and that has no match emits nothing and hands on
+    // its predecessor's end — which is an emitting entry's: a run is only dropped in front of an entry WITH a match
+    const uint32_t F0 = onT ? re : E;
+    uint32_t Fp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)F0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    Fp = lane ? Fp : prev_end;
+    const uint32_t F = (onM || onT) ? F0 : Fp;
     uint32_t pe = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)F, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     pe = lane ? pe : prev_end;
     uint32_t ms = msr > pe ? msr : pe;                                 // the previous sequence may have taken some of the zeros in front
@@ -484,6 +507,8 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         bool hv = false;
         if (DEPTH > 0) {
             const uint32_t a4 = bp_gap4(S.gbw, jj);
+            const uint8_t *gbb = reinterpret_cast<const uint8_t *>(S.gbw);
+            const uint32_t fa = jj ? (uint32_t)gbb[jj - 1u] : 0u;    // zeros in front of this one (clipped to 255)
             const uint32_t na4 = ~a4;
             const uint32_t stop4 = ((na4 - 0x01010101u) & ~na4 & 0x80808080u) | 0xFF000000u;   // a 255 agrees with nothing; 3 gaps at most
             int best = -1;
@@ -494,6 +519,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
                 const uint32_t jq = have ? jc1 : 1u;
                 const uint32_t b4 = bp_gap4(S.gbw, jq);
+                const uint32_t fb = (uint32_t)gbb[jq - 1u];
                 uint32_t nextc = 0;
                 if (CHAIN) nextc = S.chain[jq];
                 const uint32_t x = (a4 ^ b4) | stop4;
@@ -508,7 +534,9 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 const uint32_t below = (1u << (8u * k)) - 1u;
                 const uint32_t sumg = __builtin_amdgcn_sad_u8(a4 & below, 0u, k + 1u);  // their zeros + their ones + this one
                 const uint32_t za = (a4 >> (8u * k)) & 0xFFu, zb = (b4 >> (8u * k)) & 0xFFu;
-                const int score = (int)(sumg + (za < zb ? za : zb));
+                uint32_t fz = fa < fb ? fa : fb;                                        // the zeros in front a match would take along
+                fz = fz < BP_BACK ? fz : BP_BACK;
+                const int score = (int)(sumg + (za < zb ? za : zb) + fz);
                 if (have && same && score > best) {
                     best = score;
                     bjq = jq;
@@ -529,14 +557,14 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
 #pragma unroll
                 for (uint32_t s = 0; s < BP_PICK; ++s) {
                     const uint32_t g = (a4 >> (8u * s)) & 0xFFu;
-                    costR += s < bk ? 1u + (g >= BP_MINM + 1u ? 4u : g) : 0u;
+                    costR += s < bk ? 1u + (g >= BP_TMIN + 1u ? 4u : g) : 0u;
                 }
                 bool act = got;
                 for (uint32_t s = bk;; ++s) {   // (per lane: s starts at the lane's own bk; the trip count is what the wave needs)
                     if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
                     if (act) {
                         const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
-                        costR += 1u + (ga >= BP_MINM + 1u ? 4u : ga);
+                        costR += 1u + (ga >= BP_TMIN + 1u ? 4u : ga);
                         const bool cdiff = EXC && (((bp_bits(S.cls, a + 1u) ^ bp_bits(S.cls, b + 1u)) & 1u) != 0u);
                         if (s < BP_PICK || ga != gb || ga >= 255u || a >= m || s >= BP_STEPS || cdiff) {
                             const uint32_t z = ga < gb ? ga : gb;
@@ -558,7 +586,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                     const uint32_t gc = cc1 - cp1 - 1u;
                     uint32_t cnb = gq < gc ? gq : gc;
                     cnb = cnb < BP_BACK ? cnb : BP_BACK;
-                    const uint32_t costH = 3u + (clen + cnb >= 19u ? 1u : 0u) - cnb + (tailz >= BP_MINM ? 3u : tailz);
+                    const uint32_t costH = 3u + (clen + cnb >= 19u ? 1u : 0u) - cnb + (tailz >= BP_TMIN ? 3u : tailz);
                     uint32_t end = (uint32_t)q + clen;
                     end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
                     // signed compares: costH may go below zero when many zeros are pulled in
@@ -629,7 +657,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         const uint32_t rs = E + ((E == 0u || ((bp_bits(bm, E ? E - 1u : 0u) & 1u) != 0u)) ? 1u : 0u);
         uint32_t re = (uint32_t)P[(nxt < m ? nxt : m) + 1u] - 1u;   // position of the next one (n behind the last)
         re = re < BP_MATCHLIMIT ? re : BP_MATCHLIMIT;
-        const bool onT = sel && (int)re - (int)rs >= BP_MINM && rs <= BP_MFLIMIT;
+        const bool onT = sel && (int)re - (int)rs >= BP_TMIN && rs <= BP_MFLIMIT;   // (long enough; emitted or not: bp_emit_batch)
         const bool want = onM || onT;
         const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
         const uint32_t nw = (uint32_t)__builtin_popcountll(wm);
@@ -643,15 +671,18 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 qn += nw;
                 BP_MARK("queued");
             }
-            while (phase == 0 ? qn + nw > BP_QCAP : (qn >= 64u || (last && qn != 0u))) {   // (wave-uniform)
-                const uint32_t nb_ = qn < 64u ? qn : 64u;
+            // a batch leaves the queue when the entry behind its last one is there too (the run rule looks at it) — or when
+            // the stream ends
+            while (phase == 0 ? qn + nw > BP_QCAP : (qn >= 65u || (last && qn != 0u))) {   // (wave-uniform)
+                const uint32_t keep = phase == 1 && last ? 0u : 1u;
+                const uint32_t nb_ = qn - keep < 64u ? qn - keep : 64u;
                 BP_FENCE();
-                const BpOut r = bp_emit_batch<EXC>(S, bm, out, nb_, BpOut{prev_end, gop, sop}, lane);
+                const BpOut r = bp_emit_batch<EXC>(S, bm, out, nb_, qn, BpOut{prev_end, gop, sop}, lane);
                 prev_end = r.prev_end, gop = r.gop, sop = r.sop;
                 BP_FENCE();
-                const uint2 mv = lane + 64u < qn ? S.queue[64u + lane] : make_uint2(0u, 0u);
+                const uint2 mv = lane + nb_ < qn ? S.queue[nb_ + lane] : make_uint2(0u, 0u);
                 BP_FENCE();
-                if (lane + 64u < qn) S.queue[lane] = mv;
+                if (lane + nb_ < qn) S.queue[lane] = mv;
                 qn -= nb_;
             }
         }

@@ -188,7 +188,8 @@ print(total)
     for v in ("1", "0"):
         env = dict(os.environ, HHGT_LZ4_BITPLANES=v)
         sizes.append(int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.split()[-1]))
-    assert sizes[0] != sizes[1] and 0.8 < sizes[0] / sizes[1] < 1.25
+    # (the bit-plane coder packs uniform 5 % planes about a quarter tighter than the byte-wise one since round 3's run rule)
+    assert sizes[0] != sizes[1] and 0.6 < sizes[0] / sizes[1] < 1.1
 
 
 # ---- the exception-aware instantiation: planes with missing calls (bytes 0 / 1 / 0xF7), from the bit-plane form -----------

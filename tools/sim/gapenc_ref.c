@@ -15,15 +15,18 @@
 //     what that one replaced, ... — the candidate that saves most wins (depth 0: no hash matches, runs only)
 //   * candidates jc = previous ones with that key, most recent first.  The PICK among them is made on the gap bytes
 //     (gaps clipped to 255, a 255 agrees with nothing): while the gaps behind the two ones are equal (at most 3 of
-//     them) take gap + 1, then 1 + the smaller gap; the longest wins, ties go to the nearer one.  Only the winner is
+//     them) take gap + 1, then 1 + the smaller gap, plus the zeros the two have in common IN FRONT (at most 64: a match
+//     is pulled back over them); the longest wins, ties go to the nearer one.  Only the winner is
 //     evaluated exactly: its agreement may go on (to 16 gaps), costR = what coding the covered ones as literals
-//     (+ offset-1 runs for gaps >= 7) would take; tailz = zeros left of the last covered one's gap
-//   * pulled back over nb = min(8, zeros in front of q, zeros in front of the candidate) literal zeros
+//     (+ offset-1 runs for gaps >= 5) would take; tailz = zeros left of the last covered one's gap
+//   * pulled back over nb = min(64, zeros in front of q, zeros in front of the candidate) zeros
 //   * taken (hv) iff cheaper than costR, forward part >= 4, total >= 6, q <= mflimit
 //   * E = end of what the one codes (match end, else q + 1); nxt = first one at or behind E
 // The parse follows nxt from the virtual one.  Every visited one emits its match M (start clamped to the end of the
 // previous sequence) and a tail run T (offset 1) over the zeros from E (+1 if byte E-1 is a one, or E = 0) to the
-// next one, if >= 6 long.
+// next one — if there are at least 4 of them, and at least 4 that the NEXT coded one's match does not pull back over
+// anyway (a run costs 3 bytes; round 3: with the run rule blind to the pull-back and the pull-back held to 8 zeros the
+// same candidates packed 8 % looser).
 #include <stdint.h>
 #include <string.h>
 
@@ -31,7 +34,8 @@
 #define HLOG 6
 #define GAPCLIP 40
 #define MINM 6
-#define BACK 8
+#define BACK 64
+#define TMIN 4     /* zeros an offset-1 run must cover (MINM: the total length a hash match must have) */
 #define STEPS 16   /* exact extension of the chosen candidate */
 #define PICK 3     /* full gaps the pick looks at */
 
@@ -106,6 +110,11 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
                 }
                 const int za = GB[j + 1 + k], zb = GB[jc + 1 + k];
                 score += 1 + (za < zb ? za : zb);
+                {   // the zeros in front that a match from this candidate would take along
+                    const int fa = GB[j], fb = GB[jc];
+                    const int bb = fa < fb ? fa : fb;
+                    score += bb < BACK ? bb : BACK;
+                }
                 if (score > best_score) { best_score = score; bj = jc; bk = k; }
             }
             // ---- the chosen one, exactly: agreement continues past the third gap (rarely: periodic planes), then the
@@ -116,11 +125,11 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
                 int a = j + bk, b = jc + bk, clen = P[a + 1] - P[j + 1], costR = 0, tailz = 0;
                 for (int s = 0; s < bk; ++s) {
                     const int g = GB[j + 1 + s];
-                    costR += 1 + (g >= MINM + 1 ? 4 : g);
+                    costR += 1 + (g >= TMIN + 1 ? 4 : g);
                 }
                 for (int s = bk;; ++s) {
                     const int ga = P[a + 2] - P[a + 1] - 1, gb = P[b + 2] - P[b + 1] - 1;
-                    costR += 1 + (ga >= MINM + 1 ? 4 : ga);
+                    costR += 1 + (ga >= TMIN + 1 ? 4 : ga);
                     if (s < PICK || ga != gb || ga >= 255 || a + 1 >= m || s >= STEPS || cls[a + 2] != cls[b + 2]) {   // s < PICK: the pick's own verdict
                         const int z = ga < gb ? ga : gb;
                         clen += 1 + z;
@@ -133,7 +142,7 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
                 const int gq = q + 1 - P[j] - 1, gc = cc + 1 - P[jc] - 1;
                 int cnb = gq < gc ? gq : gc;
                 if (cnb > BACK) cnb = BACK;
-                const int costH = 3 + (clen + cnb >= 19 ? 1 : 0) - cnb + (tailz >= MINM ? 3 : tailz);
+                const int costH = 3 + (clen + cnb >= 19 ? 1 : 0) - cnb + (tailz >= TMIN ? 3 : tailz);
                 int end = q + clen;
                 if (end > matchlimit) end = matchlimit;
                 const int gain = costR - costH;
@@ -158,7 +167,13 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
         const int rs = e + ((e == 0 || in[e - 1]) ? 1 : 0);
         int re = P[nxt[j + 1] + 1] - 1;
         if (re > matchlimit) re = matchlimit;
-        if (re - rs >= MINM && rs <= mflimit) {
+        const int zt = re - rs, kn = nxt[j + 1];
+        int nbk = 0;   // zeros of this run that the next coded one's match starts in front of
+        if (kn < m && hv_[kn + 1]) {
+            nbk = (P[kn + 1] - 1) - ms[kn + 1];
+            if (nbk > zt) nbk = zt;
+        }
+        if (zt >= TMIN && zt - nbk >= TMIN && rs <= mflimit) {
             op = put_seq(in, out, op, prev_end, rs, re - rs, 1);
             prev_end = re;
         }
