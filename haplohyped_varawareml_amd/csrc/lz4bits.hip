@@ -47,6 +47,7 @@
 #ifndef BP_WAVES
 #define BP_WAVES 7       // waves per SIMD the plain instantiations are compiled for (LDS must allow 2 x BP_WAVES workgroups per CU)
 #endif
+#define BP_PTRASH (BP_MAXONES + 7)   // P's spare entry: written by lanes that have nothing to store, never read
 #define BP_QCAP 100     // queued coded ones a wave can hold (a window adds at most 64 to fewer than 64)
 #define BP_HLOG 6
 #define BP_GAPCLIP 40
@@ -68,13 +69,13 @@ template <bool CHAIN, bool EXC> struct BpLds {
     uint32_t xm[EXC ? 132 : 1];      // EXC: which of them are 0xF7 (missing calls)
     uint32_t cls[EXC ? 24 : 1];      // EXC: the same per ONE: bit i = the one with P-index i is a missing call
     uint32_t tab[1 << BP_HLOG];      // min(gap behind the one + 1, BP_GAPCLIP) -> one index + 1
-    uint8_t flag[72];                // pointer-doubling marks of a window
+    uint8_t flag[72];                // pointer-doubling marks of a window ([0, 64]; [68]: where lanes with nothing to mark write)
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
     uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
     uint16_t chain[CHAIN ? BP_MAXONES + 8 : 4];   // chain[j + 1] = (previous one with the same context hash) + 1, 0 = none
     uint32_t gbw[(BP_MAXONES + 16) / 4];   // gap bytes: zeros behind the one with P-index i, clipped to 255 (255 from the last one on)
-    uint2 queue[BP_QCAP];            // coded ones waiting for layout + emission (bp_emit_batch takes 64 at a time)
-    uint8_t stage[BP_STAGE];         // output staged here, written out in coalesced dwords
+    uint2 queue[BP_QCAP + 1];        // coded ones waiting for layout + emission (bp_emit_batch takes 64 at a time); [BP_QCAP]: written by lanes that queue nothing
+    uint8_t stage[BP_STAGE + 8];     // output staged here, written out in coalesced dwords; [BP_STAGE]: written by lanes that have no byte to store
 };
 
 // a queued coded one: what its sequences need that does not depend on the sequences in front of it
@@ -152,33 +153,66 @@ template <bool EXC> __device__ __forceinline__ uint32_t bp_lit(uint32_t b, uint3
     return EXC ? (((x >> k) & 1u) ? 0xF7u : v) : v;
 }
 
+#ifndef BP_EMITSKIP
+#define BP_EMITSKIP 0   // development (timing only, invalid streams): 1 no literal bytes, 2 no long literal runs, 3 no sequence bytes at all
+#endif
 // one LZ4 sequence: literals [anchor, start) (bytes generated from the bit map), match (len, off).  OUT is a pointer
 // into the staging area (LDS: ds_write_b8) or, for a window too large for it, into the stream's slot in global memory.
-template <bool EXC, typename OUT>
-__device__ __forceinline__ void bp_put_seq(const uint32_t *bm, const uint32_t *xm, OUT out, uint32_t at, uint32_t anchor, uint32_t start,
-                                           uint32_t len, uint32_t off, bool on, uint32_t lane)
+// TR: out[tr] is a byte nobody reads (staging area only) — lanes with nothing to store write there instead of sitting out
+// an exec-mask region: `if (p) store` costs two scalar instructions and often a branch, `store at (p ? a : tr)` one vector
+// select, and scalar issue is what this kernel runs out of first (probe builds).
+template <bool EXC, bool TR, typename OUT>
+__device__ __forceinline__ void bp_put_seq(const uint32_t *bm, const uint32_t *xm, OUT out, uint32_t tr, uint32_t at, uint32_t anchor,
+                                           uint32_t start, uint32_t len, uint32_t off, bool on, uint32_t lane)
 {
     const uint32_t ll = on ? start - anchor : 0u, ml = len - 4u;
     const uint32_t llx = on ? bp_len_ext(ll) : 0u, mlx = on ? bp_len_ext(ml) : 0u;
-    if (on) {
-        out[at] = (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (ml < 15u ? ml : 15u));
-        uint32_t r = ll - 15u;
-        for (uint32_t k = 0; k < llx; ++k) {   // rare: >= 15 literals
+    if (BP_EMITSKIP == 3) return;
+    // Straight-line byte stores for what nearly every sequence has — token, at most one extension byte per length,
+    // offset — and ONE wave-uniform branch for lengths that need more (>= 270).
+    const uint32_t lit = at + 1u + llx, o = lit + ll;
+    const uint32_t tok = ((ll < 15u ? ll : 15u) << 4) | (ml < 15u ? ml : 15u);
+    if (TR) {
+        out[on ? at : tr] = (uint8_t)tok;
+        out[on ? o : tr] = (uint8_t)(off & 0xFFu);
+        out[on ? o + 1u : tr] = (uint8_t)(off >> 8);
+        out[llx != 0u ? at + 1u : tr] = (uint8_t)(llx == 1u ? ll - 15u : 255u);
+        out[mlx != 0u ? o + 2u : tr] = (uint8_t)(mlx == 1u ? ml - 15u : 255u);
+    } else {
+        if (on) {
+            out[at] = (uint8_t)tok;
+            out[o] = (uint8_t)(off & 0xFFu);
+            out[o + 1u] = (uint8_t)(off >> 8);
+        }
+        if (llx != 0u) out[at + 1u] = (uint8_t)(llx == 1u ? ll - 15u : 255u);
+        if (mlx != 0u) out[o + 2u] = (uint8_t)(mlx == 1u ? ml - 15u : 255u);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(llx > 1u || mlx > 1u) != 0ull, 0)) {   // (wave-uniform, rare)
+        uint32_t r = ll - 15u - 255u;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (uint32_t k = 1; k < llx; ++k) {
             out[at + 1u + k] = (uint8_t)(k + 1u == llx ? r : 255u);
             r -= 255u;
         }
+        r = ml - 15u - 255u;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (uint32_t k = 1; k < mlx; ++k) {
+            out[o + 2u + k] = (uint8_t)(k + 1u == mlx ? r : 255u);
+            r -= 255u;
+        }
     }
-    const uint32_t lit = at + 1u + llx;
-    // literals.  Most runs are 1-3 bytes ("1", "1 0"): up to 6 go out as predicated byte stores of the owning lane.
+    // literals.  Most runs are 1-3 bytes ("1", "1 0"): up to 6 go out as byte stores of the owning lane.
     // Longer runs (the literals of all the ones in between that code nothing pile up in front of the next sequence)
     // are written by the whole wave, one run at a time — a lockstep per-lane loop would run max(ll) times for all.
-    if (__builtin_amdgcn_ballot_w64(ll != 0u) != 0ull) {
+    if (BP_EMITSKIP != 1 && __builtin_amdgcn_ballot_w64(ll != 0u) != 0ull) {
         const uint32_t b = bp_bits(bm, anchor), x = EXC ? bp_bits(xm, anchor) : 0u;
-        const bool small = ll <= 6u;
+        const uint32_t nsm = ll <= 6u ? ll : 0u;   // bytes this lane stores itself
 #pragma unroll
-        for (uint32_t k = 0; k < 6u; ++k)
-            if (small && k < ll) out[lit + k] = (uint8_t)bp_lit<EXC>(b, x, k);
-        unsigned long long big = __builtin_amdgcn_ballot_w64(ll > 6u);
+        for (uint32_t k = 0; k < 6u; ++k) {
+            if (TR) out[k < nsm ? lit + k : tr] = (uint8_t)bp_lit<EXC>(b, x, k);
+            else if (k < nsm) out[lit + k] = (uint8_t)bp_lit<EXC>(b, x, k);
+        }
+        unsigned long long big = BP_EMITSKIP == 2 ? 0ull : __builtin_amdgcn_ballot_w64(ll > 6u);
         while (big != 0ull) {
             const int l = __builtin_ctzll(big);
             big &= big - 1ull;
@@ -186,16 +220,6 @@ __device__ __forceinline__ void bp_put_seq(const uint32_t *bm, const uint32_t *x
             const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)anchor, l);
             const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)lit, l);
             for (uint32_t k = lane; k < n; k += 64u) out[dst + k] = (uint8_t)bp_lit<EXC>(bp_bits(bm, src + k), EXC ? bp_bits(xm, src + k) : 0u, 0u);
-        }
-    }
-    if (on) {
-        const uint32_t o = lit + ll;
-        out[o] = (uint8_t)(off & 0xFFu);
-        out[o + 1u] = (uint8_t)(off >> 8);
-        uint32_t r = ml - 15u;
-        for (uint32_t k = 0; k < mlx; ++k) {
-            out[o + 2u + k] = (uint8_t)(k + 1u == mlx ? r : 255u);
-            r -= 255u;
         }
     }
 }
@@ -226,13 +250,16 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
     const uint32_t *xm = S.xm;
     uint32_t prev_end = st.prev_end, gop = st.gop, sop = st.sop;
     const bool have = lane < n;
-    const uint2 en = have ? S.queue[lane] : make_uint2(0u, 0u);
+    uint2 en = S.queue[lane];   // (lane < 64 <= BP_QCAP: inside the queue whatever n is)
+    en.x = have ? en.x : 0u;
+    en.y = have ? en.y : 0u;
     const uint32_t E = en.x & 0x1FFFu, msr = (en.x >> 13) & 0x1FFFu, rs = E + (en.x >> 28), re = en.y & 0x1FFFu, off = en.y >> 13;
     const bool onM = (en.x >> 26) & 1u;
     bool onT = (en.x >> 27) & 1u;
     {   // the run is dropped when the next coded one's match starts so far in front of its one that fewer than BP_TMIN
         // zeros are left to the run (the next coded one with a match IS the next entry: msr <= re says so)
-        const uint32_t nx = lane + 1u < qn ? S.queue[lane + 1u].x : 0u;
+        uint32_t nx = S.queue[lane + 1u].x;
+        nx = lane + 1u < qn ? nx : 0u;
         const uint32_t nmsr = (nx >> 13) & 0x1FFFu;
         const bool nM = (nx >> 26) & 1u;
         uint32_t nbk = nM && nmsr <= re ? re - nmsr : 0u;
@@ -260,19 +287,19 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
     BP_MARK("sizes_done");
     // the batch's bytes go to the staging area; what is staged leaves in coalesced dwords when the next batch would not
     // fit (a batch larger than the whole area is written to global memory directly)
-    if (sop + total > BP_STAGE) {
+    if (__builtin_expect(sop + total > BP_STAGE, 0)) {
         bp_flush(S.stage, out + gop, sop, lane);
         gop += sop;
         sop = 0;
     }
     const uint32_t at = sincl - (szM + szT);
-    if (total > BP_STAGE) {   // (wave-uniform, rare: a batch with hundreds of literals)
-        bp_put_seq<EXC>(bm, xm, out + gop, at, pe, ms, lenM, off, onM, lane);
-        bp_put_seq<EXC>(bm, xm, out + gop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+    if (__builtin_expect(total > BP_STAGE, 0)) {   // (wave-uniform, rare: a batch with hundreds of literals)
+        bp_put_seq<EXC, false>(bm, xm, out + gop, 0u, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq<EXC, false>(bm, xm, out + gop, 0u, at + szM, pe2, rs, lenT, 1u, onT, lane);
         gop += total;
     } else {
-        bp_put_seq<EXC>(bm, xm, S.stage + sop, at, pe, ms, lenM, off, onM, lane);
-        bp_put_seq<EXC>(bm, xm, S.stage + sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+        bp_put_seq<EXC, true>(bm, xm, S.stage + sop, BP_STAGE - sop, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq<EXC, true>(bm, xm, S.stage + sop, BP_STAGE - sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
         sop += total;
     }
     prev_end = (uint32_t)__builtin_amdgcn_readlane((int)F, (int)(n - 1u));
@@ -433,38 +460,38 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         // (the two halves of the lane's 64 positions one after the other: each round is a count-trailing-zeros, a clear
         // and a store, and there are as many rounds as the fullest 32-position word has ones — twice ~6 — where one loop
         // over the 64-bit word ran ~11 rounds of twice the work)
+        // (no `if (lo != 0)` around the body: a lane that has run out stores to P's spare entry — an exec-mask region costs
+        // two scalar instructions and a branch per round, and scalar issue is this kernel's tightest port)
         uint32_t lo = wlo, hi = whi, at = incl - cnt + 1u;
-        if (lane == 0) P[0] = 0;
+        P[lane == 0u ? 0u : BP_PTRASH] = 0;
         uint32_t base = 64u * lane + 1u;
         while (__builtin_amdgcn_ballot_w64(lo != 0u) != 0ull) {
-            if (lo != 0u) {
-                const uint32_t bpos = (uint32_t)__builtin_ctz(lo);
-                if (EXC && ((xlo >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));   // (LDS: ds_or_b32)
-                P[at++] = (uint16_t)(base + bpos);
-                lo &= lo - 1u;
-            }
+            const bool on = lo != 0u;
+            const uint32_t bpos = (uint32_t)__builtin_ctz(lo | 0x80000000u);
+            if (EXC && on && ((xlo >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));   // (LDS: ds_or_b32)
+            P[on ? at : BP_PTRASH] = (uint16_t)(base + bpos);
+            at += on ? 1u : 0u;
+            lo &= lo - 1u;
         }
         base += 32u;
         while (__builtin_amdgcn_ballot_w64(hi != 0u) != 0ull) {
-            if (hi != 0u) {
-                const uint32_t bpos = (uint32_t)__builtin_ctz(hi);
-                if (EXC && ((xhi >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));
-                P[at++] = (uint16_t)(base + bpos);
-                hi &= hi - 1u;
-            }
+            const bool on = hi != 0u;
+            const uint32_t bpos = (uint32_t)__builtin_ctz(hi | 0x80000000u);
+            if (EXC && on && ((xhi >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));
+            P[on ? at : BP_PTRASH] = (uint16_t)(base + bpos);
+            at += on ? 1u : 0u;
+            hi &= hi - 1u;
         }
-        if (lane < 4u) P[m + 1u + lane] = (uint16_t)(BP_N + 1);
+        P[lane < 4u ? m + 1u + lane : BP_PTRASH] = (uint16_t)(BP_N + 1);
     }
     BP_FENCE();
     if (DEPTH > 0) {   // gap bytes of all ones (a candidate is compared on them, 4 at a time)
         uint8_t *gb = reinterpret_cast<uint8_t *>(S.gbw);
         for (uint32_t i = lane; i < m + 8u; i += 64u) {
-            uint32_t g = 255u;
-            if (i < m) {
-                g = (uint32_t)P[i + 1u] - (uint32_t)P[i] - 1u;
-                g = g < 255u ? g : 255u;
-            }
-            gb[i] = (uint8_t)g;
+            const uint32_t i1 = i + 1u < BP_PTRASH ? i + 1u : BP_PTRASH;   // (i < m + 8 <= 644: the loads stay inside P)
+            uint32_t g = (uint32_t)P[i1] - (uint32_t)P[i1 - 1u] - 1u;
+            g = g < 255u ? g : 255u;
+            gb[i] = (uint8_t)(i < m ? g : 255u);
         }
         BP_FENCE();
     }
@@ -480,6 +507,17 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
     int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
     for (int jw = -1; jw < (int)m; jw += 64) {
         BP_MARK("win_begin");
+#ifdef BP_PROBE_SALU   // development: extra independent scalar / vector instructions per window — which issue port is the tight one?
+#pragma unroll
+        for (int pr = 0; pr < BP_PROBE_SALU; ++pr) asm volatile("s_mov_b32 s90, 0" ::: "s90");
+#endif
+#ifdef BP_PROBE_VALU
+        {
+            uint32_t pv;
+#pragma unroll
+            for (int pr = 0; pr < BP_PROBE_VALU; ++pr) asm volatile("v_mov_b32 %0, 0" : "=v"(pv));
+        }
+#endif
         const int j = jw + (int)lane;
         const bool valid = j < (int)m;
         const uint32_t jj = valid ? (uint32_t)(j + 1) : 0u;          // index into P of this one
@@ -537,11 +575,10 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 uint32_t fz = fa < fb ? fa : fb;                                        // the zeros in front a match would take along
                 fz = fz < BP_BACK ? fz : BP_BACK;
                 const int score = (int)(sumg + (za < zb ? za : zb) + fz);
-                if (have && same && score > best) {
-                    best = score;
-                    bjq = jq;
-                    bk = k;
-                }
+                const bool up = have & same & (score > best);   // (selects, not a branch)
+                best = up ? score : best;
+                bjq = up ? jq : bjq;
+                bk = up ? k : bk;
                 if (!CHAIN) break;
                 jc1 = have ? nextc : 0u;
             }
@@ -552,7 +589,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 const uint32_t jq = got ? bjq : 1u;
                 const uint32_t cc1 = P[jq], cp1 = P[jq - 1u];
                 uint32_t a = jj + bk, b = jq + bk;          // P-indices of the ones the first open comparison starts at
-                uint32_t pa = P[a], na = P[a + 1u], pb = P[b], nbn = P[b + 1u];
+                uint32_t pa = P[a], pb = P[b];
                 uint32_t clen = pa - q1, costR = 0, tailz = 0;
 #pragma unroll
                 for (uint32_t s = 0; s < BP_PICK; ++s) {
@@ -562,27 +599,22 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 bool act = got;
                 for (uint32_t s = bk;; ++s) {   // (per lane: s starts at the lane's own bk; the trip count is what the wave needs)
                     if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-                    if (act) {
-                        const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
-                        costR += 1u + (ga >= BP_TMIN + 1u ? 4u : ga);
-                        const bool cdiff = EXC && (((bp_bits(S.cls, a + 1u) ^ bp_bits(S.cls, b + 1u)) & 1u) != 0u);
-                        if (s < BP_PICK || ga != gb || ga >= 255u || a >= m || s >= BP_STEPS || cdiff) {
-                            const uint32_t z = ga < gb ? ga : gb;
-                            clen += 1u + z;
-                            tailz = ga - z;
-                            act = false;
-                        } else {
-                            clen += 1u + ga;
-                            ++a;
-                            ++b;
-                            pa = na;
-                            pb = nbn;
-                            na = P[a + 1u];
-                            nbn = P[b + 1u];
-                        }
-                    }
+                    // (branch-free body: lanes that are done keep their values through selects; a + 1, b + 1 <= m + 4 stay inside P)
+                    const uint32_t na = P[a + 1u], nbn = P[b + 1u];
+                    const uint32_t ga = na - pa - 1u, gb = nbn - pb - 1u;
+                    const bool cdiff = EXC && (((bp_bits(S.cls, a + 1u) ^ bp_bits(S.cls, b + 1u)) & 1u) != 0u);
+                    const bool stop = (s < BP_PICK) | (ga != gb) | (ga >= 255u) | (a >= m) | (s >= BP_STEPS) | cdiff;
+                    const uint32_t z = ga < gb ? ga : gb;
+                    costR += act ? 1u + (ga >= BP_TMIN + 1u ? 4u : ga) : 0u;
+                    clen += act ? 1u + (stop ? z : ga) : 0u;
+                    tailz = (act & stop) ? ga - z : tailz;
+                    act = act & !stop;
+                    a += act ? 1u : 0u;
+                    b += act ? 1u : 0u;
+                    pa = act ? na : pa;
+                    pb = act ? nbn : pb;
                 }
-                if (got) {
+                {
                     const uint32_t gc = cc1 - cp1 - 1u;
                     uint32_t cnb = gq < gc ? gq : gc;
                     cnb = cnb < BP_BACK ? cnb : BP_BACK;
@@ -591,12 +623,10 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                     end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
                     // signed compares: costH may go below zero when many zeros are pulled in
                     const int gain = (int)costR - (int)costH;
-                    if (gain > 0 && (int)end - q >= 4 && (int)end - (q - (int)cnb) >= BP_MINM && q <= BP_MFLIMIT) {
-                        hv = true;
-                        len = end - (uint32_t)q;
-                        nb = cnb;
-                        c1 = cc1;
-                    }
+                    hv = got & (gain > 0) & ((int)end - q >= 4) & ((int)end - (q - (int)cnb) >= BP_MINM) & (q <= BP_MFLIMIT);   // (& not &&: no nest of exec-mask regions)
+                    len = hv ? end - (uint32_t)q : 0u;
+                    nb = hv ? cnb : 0u;
+                    c1 = hv ? cc1 : 0u;
                 }
             }
         }
@@ -605,15 +635,12 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         // first one at or behind E: ones in front of bit E of the map
         uint32_t nxt;
         {
-            const uint32_t w = E >> 6, bb = E & 63u;
-            if (w >= 64u) {
-                nxt = m;
-            } else {
-                const uint32_t lo = bm[2u * w], hi = bm[2u * w + 1u];
-                const uint32_t mlo = bb >= 32u ? 0xFFFFFFFFu : ((1u << bb) - 1u);
-                const uint32_t mhi = bb > 32u ? ((1u << (bb - 32u)) - 1u) : 0u;
-                nxt = (uint32_t)wpre[w] + (uint32_t)__popc(lo & mlo) + (uint32_t)__popc(hi & mhi);
-            }
+            const uint32_t w = E >> 6, bb = E & 63u, wc = w < 63u ? w : 63u;
+            const uint32_t lo = bm[2u * wc], hi = bm[2u * wc + 1u];
+            const uint32_t mlo = bb >= 32u ? 0xFFFFFFFFu : ((1u << bb) - 1u);
+            const uint32_t mhi = bb > 32u ? ((1u << (bb - 32u)) - 1u) : 0u;
+            const uint32_t in_map = (uint32_t)wpre[wc] + (uint32_t)__popc(lo & mlo) + (uint32_t)__popc(hi & mhi);
+            nxt = w >= 64u ? m : in_map;
         }
         BP_MARK("nxt_done");
         // ---- which ones of the window are coded: follow nxt from `cur` by pointer doubling.  (Measured against the plain
@@ -629,12 +656,12 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
             uint32_t jump = valid ? (nxt - (uint32_t)jw < 64u ? nxt - (uint32_t)jw : 64u) : 64u;   // nxt > j: always forward
             const uint32_t p0 = jump;
             flag[lane] = lane == e0 ? 1u : 0u;
-            if (lane == 0) flag[64] = 0u;
+            flag[lane == 0u ? 64u : 69u] = 0u;
             BP_FENCE();
             bool reach = lane == e0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                if (reach) flag[jump] = 1u;
+                flag[reach ? jump : 68u] = 1u;   // (no exec-mask region: a scalar instruction costs this kernel four times a vector one)
                 BP_FENCE();
                 reach = flag[lane] != 0u;
                 const uint32_t j2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jump & 63u) << 2), (int)jump);
@@ -667,7 +694,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         for (int phase = 0; phase < 2; ++phase) {
             if (phase == 1) {
                 const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-                if (want) S.queue[slot] = bp_entry(E, (uint32_t)(q - (int)nb), onM, onT, rs, re, q1 - c1);
+                S.queue[want ? slot : (uint32_t)BP_QCAP] = bp_entry(E, (uint32_t)(q - (int)nb), onM, onT, rs, re, q1 - c1);
                 qn += nw;
                 BP_MARK("queued");
             }
@@ -680,9 +707,10 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 const BpOut r = bp_emit_batch<EXC>(S, bm, out, nb_, qn, BpOut{prev_end, gop, sop}, lane);
                 prev_end = r.prev_end, gop = r.gop, sop = r.sop;
                 BP_FENCE();
-                const uint2 mv = lane + nb_ < qn ? S.queue[nb_ + lane] : make_uint2(0u, 0u);
+                const bool mvp = lane + nb_ < qn;
+                const uint2 mv = S.queue[mvp ? nb_ + lane : (uint32_t)BP_QCAP];
                 BP_FENCE();
-                if (lane + nb_ < qn) S.queue[lane] = mv;
+                S.queue[mvp ? lane : (uint32_t)BP_QCAP] = mv;
                 qn -= nb_;
             }
         }
