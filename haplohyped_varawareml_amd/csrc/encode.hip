@@ -610,9 +610,50 @@ __device__ __forceinline__ uint32_t parse_gt_bytes(RD rd, uint32_t p, uint32_t l
 }
 
 #define GEN_HALO 64u  // bytes staged past each 1 KiB piece: a GT sub-field that starts in the piece ends inside it
+#define GEN_IMG_MAX_S 24576u   // widest cohort whose line image (4 bits per sample) a wave keeps in LDS: 12 KiB
+
+// 16 bytes of the text at `at` if they lie inside it, else what there is (zero-filled): the last line of a text may end
+// within 16 bytes of the buffer's end
+__device__ __forceinline__ uint4 gen_load16(const uint8_t *__restrict__ text, uint64_t n, uint64_t at)
+{
+    if (at + 16ull <= n) {
+        const u32x4_unaligned t = *reinterpret_cast<const u32x4_unaligned *>(text + at);
+        return make_uint4(t.x, t.y, t.z, t.w);
+    }
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t k = 0; k < 16u; ++k)
+        if (at + k < n) w[k >> 2] |= (uint32_t)text[at + k] << (8u * (k & 3u));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// inclusive wave scan of small counts on DPP row shifts (no LDS round trips)
+__device__ __forceinline__ uint32_t gen_scan_incl(uint32_t x, uint32_t lane)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 15);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 31) + t0;
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 47) + t1;
+    const uint32_t row = lane >> 4;
+    return x + (row == 0u ? 0u : (row == 1u ? t0 : (row == 2u ? t1 : t2)));
+}
 
 // PLANES: the bit-plane form (k_encode_planes wrote zeros for every call of the lines this kernel owns; the bits are set
-// by atomic or, the bytes of calls beyond 0 / 1 / missing go to their place in G)
+// by atomic or, the bytes of calls beyond 0 / 1 / missing go to their place in G).
+// One wave per line, 1 KiB pieces.  Lane l holds bytes [16 l, 16 l + 16) of the piece and finds its tabs (one bit per
+// byte); a wave scan numbers them, and every lane writes where the columns behind its tabs start into a list in LDS.
+// Then the COLUMNS are dealt to the lanes, 64 consecutive samples per round: four bytes at the column's start from the
+// staged piece, the branch-free {0, 1, .} x {|, /} classification of the tile kernel's second level (anything else:
+// the byte walk of the GT rule, lane by lane), and the round's ONE / EXC bits of both haplotypes are four ballots —
+// the nonzero calls go to the planes as global atomic ors (other lines of the same 32-variant group set their bits in the
+// same dwords).  With img_words != 0 (development, launch_encode_general) the round's bits are four ballots merged into an
+// LDS image of the line instead, which goes to the planes at the end of the line.
+// Round 3, after config 4 spent 3.8 of 16 ms here (88 k `GT:DP` lines at 115 GB/s): the first version dealt the BYTES
+// to the lanes and let every lane loop over the columns that start in its 16 (two or three half-empty iterations per
+// piece); this one runs 3.6 ms.  Prefetching the next piece and collecting the atomics per line changed nothing or made
+// it worse: what is left is the rate of sparse device-scope atomics, one per nonzero call, each to its own 32-byte piece.
 template <bool PLANES>
 __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restrict__ text, uint64_t n,
                                                         const uint32_t *__restrict__ k_soff,
@@ -621,7 +662,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                                                         const uint32_t *__restrict__ redo_list,
                                                         const uint64_t *__restrict__ d_cursor,
                                                         LayoutDev lay, int8_t *__restrict__ G, uint8_t *__restrict__ P,
-                                                        DevCounters *cnt)
+                                                        DevCounters *cnt, uint32_t img_words)
 {
     const uint64_t v_base = *d_cursor;
     const PlanesGeom pgeom = planes_geom(lay, 0u);
@@ -630,14 +671,16 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t n_redo = (uint32_t)cnt->n_general;
     const uint32_t S = lay.S;
-    // each wave stages the 1 KiB piece it is ranking (plus a halo) in LDS: the per-field byte walk then reads LDS
-    // instead of issuing one global load per character
-    __shared__ __attribute__((aligned(16))) uint8_t sbuf[4][1024 + GEN_HALO];
+    __shared__ __attribute__((aligned(16))) uint8_t sbuf[4][1024 + GEN_HALO];   // the piece (plus a halo), per wave
+    __shared__ uint16_t slist[4][1024];                                          // where its columns start
+    extern __shared__ __attribute__((aligned(16))) uint32_t gen_img[];   // [4 waves][4 kind-planes][img_words]; img_words = 0: no image
     // (the staged piece is always reached as sbuf[wq][...]: through a pointer variable the reader lambda below lost the LDS
     // address space and every character was a flat_load — 915 global-load instructions per line, 520 us per line)
     const uint32_t wq = threadIdx.x >> 6;
 #define buf (sbuf[wq])
-    uint32_t haploid = 0, malformed = 0;
+    const bool use_img = PLANES && img_words != 0u;
+    uint32_t *img = gen_img + (size_t)wq * 4u * img_words;
+    uint32_t haploid = 0, malformed = 0, n_other = 0;
     for (uint32_t idx = wave; idx < n_redo; idx += n_waves) {
         const uint32_t k = redo_list[idx];
         const uint32_t soff = k_soff[k], lend = k_lend[k], gtidx = k_meta[k] >> 8;
@@ -652,42 +695,38 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         const uint32_t pmask = 1u << ((uint32_t)(vin % PL_TILE) & 31u);
         const uint32_t rs = soff - 1u;  // the 9th tab: every sample field is preceded by a tab in [rs, lend)
         uint32_t tabs_before = 0, nl_inside = 0;
+        if (use_img)
+            for (uint32_t w = lane; w < 4u * img_words; w += 64u) img[w] = 0u;
+        // software pipeline: the piece in `cur` / `hal` was loaded one iteration ago
+        uint4 cur = gen_load16(text, n, (uint64_t)rs + 16u * lane);
+        uint4 hal = lane < GEN_HALO / 16u ? gen_load16(text, n, (uint64_t)rs + 1024u + 16u * lane) : make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t base = rs; base < lend; base += 1024u) {
             const uint32_t b0 = base + 16u * lane;
+            const bool more = base + 1024u < lend;   // (wave-uniform)
+            uint4 nx = make_uint4(0u, 0u, 0u, 0u), nh = nx;
+            if (more) {
+                nx = gen_load16(text, n, (uint64_t)b0 + 1024u);
+                if (lane < GEN_HALO / 16u) nh = gen_load16(text, n, (uint64_t)base + 2048u + 16u * lane);
+            }
+            *reinterpret_cast<uint4 *>(buf + 16u * lane) = cur;
+            if (lane < GEN_HALO / 16u) *reinterpret_cast<uint4 *>(buf + 1024u + 16u * lane) = hal;
+            // exact per-byte "== tab" mask (SWAR), 4 bits per dword; bytes at or behind the line's end do not count
             uint32_t m = 0;
-            if (b0 + 16u <= lend) {
-                // one unaligned 16-byte load + exact per-byte "== tab" mask (SWAR), 4 bits per dword
-                const u32x4_unaligned t4 = *reinterpret_cast<const u32x4_unaligned *>(text + b0);
-                const uint32_t wv[4] = {t4.x, t4.y, t4.z, t4.w};
-                *reinterpret_cast<uint4 *>(buf + 16u * lane) = make_uint4(t4.x, t4.y, t4.z, t4.w);
+            {
+                const uint32_t wv[4] = {cur.x, cur.y, cur.z, cur.w};
+                const uint32_t inl = b0 >= lend ? 0u : (lend - b0 >= 16u ? 0xFFFFu : ((1u << (lend - b0)) - 1u));
+                uint32_t nlm = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t t = wv[q] ^ 0x09090909u;
                     const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
                     m |= ((((z >> 7) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
                     const uint32_t tn = wv[q] ^ 0x0A0A0A0Au;
-                    nl_inside |= (tn - 0x01010101u) & ~tn & 0x80808080u;   // a newline in front of the line's own
+                    const uint32_t zn = ~(((tn & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | tn | 0x7F7F7F7Fu);
+                    nlm |= ((((zn >> 7) * 0x01020408u) >> 24) & 0xFu) << (4 * q);
                 }
-            } else if (b0 < lend) {
-                for (uint32_t j = 0; j < 16u; ++j) {
-                    uint32_t p = b0 + j;
-                    if (p < lend) {
-                        const uint8_t ch = text[p];
-                        buf[16u * lane + j] = ch;
-                        if (ch == '\t') m |= 1u << j;
-                        if (ch == '\n') nl_inside = 1u;
-                    }
-                }
-            }
-            if (lane < GEN_HALO / 16u) {
-                const uint32_t hb = base + 1024u + 16u * lane;
-                if (hb + 16u <= lend) {
-                    const u32x4_unaligned h4 = *reinterpret_cast<const u32x4_unaligned *>(text + hb);
-                    *reinterpret_cast<uint4 *>(buf + 1024u + 16u * lane) = make_uint4(h4.x, h4.y, h4.z, h4.w);
-                } else {
-                    for (uint32_t j = 0; j < 16u; ++j)
-                        if (hb + j < lend) buf[1024u + 16u * lane + j] = text[hb + j];
-                }
+                m &= inl;
+                nl_inside |= nlm & inl;   // a newline in front of the line's own
             }
             const uint32_t avail = lend - base < 1024u + GEN_HALO ? lend - base : 1024u + GEN_HALO;
             // the staged piece through a pointer that CARRIES the LDS address space: as a generic pointer (or as one arm of a
@@ -699,35 +738,45 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 if (o < avail) return (uint32_t)lbuf[o];
                 return (uint32_t)text[p];  // beyond the halo: rare long sub-fields
             };
-            uint32_t c = __popc(m), inc = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t t = __shfl_up(inc, d, 64);
-                if (lane >= (uint32_t)d) inc += t;
+            // the columns that start in this piece, in order: slist[i] = offset of the byte behind the i-th tab
+            const uint32_t c = __popc(m);
+            const uint32_t inc = gen_scan_incl(c, lane);
+            const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            {
+                uint32_t at = inc - c, mm = m;
+                while (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
+                    const bool on = mm != 0u;
+                    const uint32_t j = (uint32_t)__builtin_ctz(mm | 0x10000u);
+                    slist[wq][on ? at : 1023u] = (uint16_t)(16u * lane + j + 1u);   // (slot 1023 is never a column's: a piece with 1024 tabs has its last one at offset 1023, written by an `on` lane)
+                    at += on ? 1u : 0u;
+                    mm &= mm - 1u;
+                }
             }
-            uint32_t f = tabs_before + inc - c;
-            while (m) {
-                int j = __ffs(m) - 1;
-                m &= m - 1;
-                const uint32_t s = f++;
-                if (s >= S) continue;  // surplus columns are not decoded (the oracle ignores them too)
-                uint32_t p = b0 + (uint32_t)j + 1u;
+            for (uint32_t r0 = 0; r0 < nf; r0 += 64u) {   // (wave-uniform trip count)
+                const uint32_t i = r0 + lane;
+                const uint32_t s = tabs_before + i;
+                const bool act = i < nf && s < S;   // surplus columns are not decoded (the oracle ignores them too)
+                const uint32_t o0 = (uint32_t)slist[wq][i < 1024u ? i : 1023u];
+                uint32_t p = base + (act ? o0 : 1u);
                 bool missing = false;
-                for (uint32_t gsk = 0; gsk < gtidx; ++gsk) {  // skip to the GT sub-field
-                    while (p < lend && rd(p) != ':' && rd(p) != '\t') ++p;
-                    if (p < lend && rd(p) == ':') ++p;
-                    else {
-                        missing = true;
-                        break;
+                if (gtidx != 0u && act) {
+                    for (uint32_t gsk = 0; gsk < gtidx; ++gsk) {  // skip to the GT sub-field
+                        while (p < lend && rd(p) != ':' && rd(p) != '\t') ++p;
+                        if (p < lend && rd(p) == ':') ++p;
+                        else {
+                            missing = true;
+                            break;
+                        }
                     }
                 }
-                uint32_t na = 1, hv = 0xF7F7u;
+                uint32_t na = 2u, hv = 0xF7F7u;
                 bool done = false;
-                if (gtidx == 0u && p - base + 8u <= avail) {
+                {
                     // the common column: GT comes first and reads "a|b" / "a/b" with a, b in {0, 1, .}, closed by ':', a tab or
                     // the line end.  Four bytes from the staged piece (two aligned dwords, one funnel shift), the same
                     // branch-free classification as the tile kernel's second level.
-                    const uint32_t o = p - base;
+                    const bool inb = p - base + 8u <= avail;
+                    const uint32_t o = inb ? p - base : 0u;
                     const uint32_t *w32 = reinterpret_cast<const uint32_t *>(sbuf[wq]);
                     uint32_t x = __builtin_amdgcn_alignbyte(w32[(o >> 2) + 1u], w32[o >> 2], o & 3u);
                     if (p + 3u >= lend) x = (x & 0x00FFFFFFu) | 0x09000000u;   // the line (and the text) ends behind the call
@@ -738,48 +787,78 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                     const uint32_t want = __umul24(e2, 30u) | (y & 0x00010001u & ~e2);
                     const uint32_t z = y & 0x0000FF00u, zz = z ^ 0x00005300u;
                     const uint32_t off = ((y & 0x00FF00FFu) ^ want) | (z < zz ? z : zz);
-                    if (off == 0u && (yt == 0u || yt == 0x03u || yt == 0x33u) && p + 3u <= lend) {
-                        const uint32_t h0 = (e2 & 1u) ? 0xF7u : (o2 & 1u), h1 = (e2 >> 16) ? 0xF7u : (o2 >> 16);
-                        hv = h0 | (h1 << 8);
-                        na = 2u;
-                        done = true;
+                    done = inb & !missing & (off == 0u) & ((yt == 0u) | (yt == 0x03u) | (yt == 0x33u)) & (p + 3u <= lend);
+                    const uint32_t h0 = (e2 & 1u) ? 0xF7u : (o2 & 1u), h1 = (e2 >> 16) ? 0xF7u : (o2 >> 16);
+                    hv = done ? (h0 | (h1 << 8)) : 0xF7F7u;
+                }
+                if (__builtin_amdgcn_ballot_w64(act && !done && !missing) != 0ull) {   // (wave-uniform: some lane needs the byte walk)
+                    if (act && !done && !missing) {
+                        na = 1u;
+                        // the sub-field ends at ':' or at the column's tab; both stop the GT rule
+                        hv = parse_gt_bytes(rd, p, lend, &na);
                     }
                 }
-                if (!done && !missing) {
-                    // the sub-field ends at ':' or at the column's tab; both stop the GT rule
-                    hv = parse_gt_bytes(rd, p, lend, &na);
-                }
-                if (na == 1u) ++haploid;
+                if (act && missing) na = 1u;   // a column without the GT sub-field counts as one missing allele (parse_gt_bytes of nothing)
+                if (act && na == 1u) ++haploid;
                 auto g_off = [&]() -> uint64_t {   // the call's place in the int8 matrix (64-bit multiplies: only where it is needed)
                     const uint32_t scol = lay.sc_log2 >= 31u ? 0u : (s >> lay.sc_log2);
                     const uint32_t sin = s - scol * lay.Sc;
                     return (((vcol * lay.n_sc + scol) * lay.Sc + sin) * lay.Vc + vin) * 2ull;
                 };
                 if (!PLANES) {
-                    *reinterpret_cast<uint16_t *>(G + g_off()) = (uint16_t)hv;
+                    if (act) *reinterpret_cast<uint16_t *>(G + g_off()) = (uint16_t)hv;
                 } else {
-                    // (pline: the line's tile and bit are the same for every sample — wave-uniform, computed once per line)
-                    uint32_t *pw = reinterpret_cast<uint32_t *>(pline + (uint64_t)s * 32ull);
                     const uint32_t h0 = hv & 0xFFu, h1 = (hv >> 8) & 0xFFu;
-                    if (h0 == 1u || h0 == 0xF7u) atomicOr(pw, pmask);
-                    if (h1 == 1u || h1 == 0xF7u) atomicOr(pw + kstride, pmask);
-                    if (h0 > 1u) {
-                        atomicOr(pw + 2ull * kstride, pmask);
-                        if (h0 != 0xF7u) {
-                            atomicAdd(&cnt->n_other, 1ull);
-                            if (G) G[g_off()] = (int8_t)h0;
+                    // kind-planes of a tile: ONE of haplotype 0, ONE of haplotype 1, EXC of haplotype 0, EXC of haplotype 1
+                    const bool bk[4] = {act && (h0 == 1u || h0 == 0xF7u), act && (h1 == 1u || h1 == 0xF7u), act && h0 > 1u, act && h1 > 1u};
+                    if (use_img) {
+                        // lane l of the round is sample s_r + l: a ballot is 64 consecutive samples of one kind-plane
+                        const uint32_t s_r = tabs_before + r0, w0 = s_r >> 5, sh = s_r & 31u;
+#pragma unroll
+                        for (int kp = 0; kp < 4; ++kp) {
+                            const unsigned long long B = __builtin_amdgcn_ballot_w64(bk[kp]);
+                            if (B != 0ull) {   // (wave-uniform)
+                                const unsigned long long lo = B << sh, hi = sh ? B >> (64u - sh) : 0ull;
+                                const uint32_t part = lane == 0u ? (uint32_t)lo : (lane == 1u ? (uint32_t)(lo >> 32) : (uint32_t)hi);
+                                if (lane < 3u && w0 + lane < img_words) img[(uint32_t)kp * img_words + w0 + lane] |= part;
+                            }
                         }
+                    } else {
+                        // (pline: the line's tile and bit are the same for every sample — wave-uniform, computed once per line)
+                        uint32_t *pw = reinterpret_cast<uint32_t *>(pline + (uint64_t)s * 32ull);
+                        if (bk[0]) atomicOr(pw, pmask);
+                        if (bk[1]) atomicOr(pw + kstride, pmask);
+                        if (bk[2]) atomicOr(pw + 2ull * kstride, pmask);
+                        if (bk[3]) atomicOr(pw + 3ull * kstride, pmask);
                     }
-                    if (h1 > 1u) {
-                        atomicOr(pw + 3ull * kstride, pmask);
-                        if (h1 != 0xF7u) {
-                            atomicAdd(&cnt->n_other, 1ull);
-                            if (G) G[g_off() + 1ull] = (int8_t)h1;
-                        }
+                    if (bk[2] && h0 != 0xF7u) {
+                        ++n_other;
+                        if (G) G[g_off()] = (int8_t)h0;
+                    }
+                    if (bk[3] && h1 != 0xF7u) {
+                        ++n_other;
+                        if (G) G[g_off() + 1ull] = (int8_t)h1;
                     }
                 }
             }
-            tabs_before += __shfl(inc, 63, 64);
+            tabs_before += nf;
+            cur = nx;
+            hal = nh;
+        }
+        if (use_img) {
+            // the line's calls go to the planes: lane l owns samples [32 w, 32 w + 32) for w = l, l + 64, ...; one global
+            // atomic per set bit (other lines of the same 32-variant group may be setting theirs in the same dwords)
+            for (uint32_t kp = 0; kp < 4u; ++kp) {
+                for (uint32_t w = lane; w < img_words; w += 64u) {
+                    uint32_t bits = img[kp * img_words + w];
+                    while (bits) {
+                        const uint32_t b = (uint32_t)__ffs(bits) - 1u;
+                        bits &= bits - 1u;
+                        uint32_t *pw = reinterpret_cast<uint32_t *>(pline + (uint64_t)(32u * w + b) * 32ull);
+                        atomicOr(pw + (uint64_t)kp * kstride, pmask);
+                    }
+                }
+            }
         }
         // fewer sample columns than the header declares; or a line end inside the line: a line shorter than any record
         // with S samples can be (its newline lay in the part the hopping index does not look at, index.hip)
@@ -788,10 +867,14 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
     }
     // one atomic per wave
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) haploid += __shfl_down(haploid, d, 64);
+    for (int d = 32; d > 0; d >>= 1) {
+        haploid += __shfl_down(haploid, d, 64);
+        n_other += __shfl_down(n_other, d, 64);
+    }
     if (lane == 0) {
         if (haploid) atomicAdd(&cnt->n_haploid, (unsigned long long)haploid);
         if (malformed) atomicAdd(&cnt->n_malformed, (unsigned long long)malformed);
+        if (n_other) atomicAdd(&cnt->n_other, (unsigned long long)n_other);
     }
 }
 #undef buf
@@ -886,12 +969,18 @@ int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_s
                           int8_t *d_G, uint8_t *d_P, DevCounters *d_cnt, int n_cu, hipStream_t st)
 {
     if (lay.S == 0) return HHGT_OK;
+    // HHGT_GEN_IMG=1: every wave keeps the calls of its line in an LDS image (4 bits per sample, merged from ballots) and sends
+    // them to the planes at the end of the line.  Measured on config 4: 4.3 ms against 3.6 ms with the atomics issued from
+    // the column rounds — the ~70 M sparse device-scope atomics per pass (one per nonzero call, each to its own 32-byte
+    // piece) are what this kernel waits for either way, and a burst of them at the end of a line hides worse.  Off by default.
+    static const bool img_env = getenv("HHGT_GEN_IMG") && atoi(getenv("HHGT_GEN_IMG")) == 1;
+    const uint32_t img_words = d_P && img_env && lay.S <= GEN_IMG_MAX_S ? (lay.S + 31u) / 32u : 0u;
     if (d_P)
-        hipLaunchKernelGGL(k_encode_general<true>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
-                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt);
+        hipLaunchKernelGGL(k_encode_general<true>, dim3((uint32_t)n_cu * 8u), dim3(256), (size_t)img_words * 64u, st, d_text, n, k_soff,
+                           k_lend, k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt, img_words);
     else
         hipLaunchKernelGGL(k_encode_general<false>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
-                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt);
+                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt, 0u);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
