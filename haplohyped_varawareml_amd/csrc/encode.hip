@@ -845,6 +845,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
             cur = nx;
             hal = nh;
         }
+#ifndef GEN_NO_SCATTER   // (development: timing of the column rounds alone; invalid planes)
         if (use_img) {
             // the line's calls go to the planes: lane l owns samples [32 w, 32 w + 32) for w = l, l + 64, ...; one global
             // atomic per set bit (other lines of the same 32-variant group may be setting theirs in the same dwords)
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                 }
             }
         }
+#endif
         // fewer sample columns than the header declares; or a line end inside the line: a line shorter than any record
         // with S samples can be (its newline lay in the part the hopping index does not look at, index.hip)
         const bool broken = __builtin_amdgcn_ballot_w64(nl_inside != 0u) != 0ull;

@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
 // unchanged), looks at the first byte of the next line ('#' header lines and empty lines are short: no skip behind
 // them) and hops.  The first newline of a wave's range is found by plain scanning, so ranges need no hand-over.
 // A line that IS shorter than the bound (fewer sample columns than the header declares) is malformed either way; when
-// its newline falls into a hop it merges with the next line, and the general encoder reports the newline it then
-// finds inside the sample columns (encode.hip) — the same error, one record later.
+// its newline falls into a hop it merges with the next line, and the newline is found where the merged line is read:
+// by the general encoder inside the sample columns of a KEPT record (encode.hip), by k_parse_fixed in the skipped bytes
+// of a record the filters DROP (nobody else reads those) — the same error, one record later.
 template <int U, uint32_t HOP_K>
 __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ slots,
                                                    uint32_t *__restrict__ counts, uint32_t n_regions, uint32_t skip,
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ l_soff, uint32_t *__restrict__ l_lend,
                                                      uint32_t *__restrict__ l_pos, uint32_t *__restrict__ l_refalt,
                                                      uint32_t *__restrict__ l_flags, uint32_t *__restrict__ l_keep,
-                                                     uint32_t *__restrict__ l_cnew, DevCounters *cnt)
+                                                     uint32_t *__restrict__ l_cnew, DevCounters *cnt, uint32_t hop_skip)
 {
     HHGT_WAVE_PRIO();
     // The walk below is byte-serial per line; straight from global memory that is ~80 dependent loads per lane with
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
     __syncthreads();
     const uint8_t *mine = reinterpret_cast<const uint8_t *>(stage[threadIdx.x]);
     auto rd = [&](uint32_t x) -> uint32_t { return (staged && x - s < 64u) ? (uint32_t)mine[x - s] : (uint32_t)text[x]; };
+    uint32_t soff = 0, pos0 = 0, refalt = 0, gtidx = 0;
     if (i < n_lines) {
         if (e > s && rd(e - 1u) == '\r') --e;  // bgzf_getline strips a trailing CR
-        uint32_t soff = e, pos0 = 0, refalt = 0, gtidx = 0;
+        soff = e;
         if (e > s && rd(s) != '#') {
             flags = LF_RECORD;
             // walk the first 9 tab-separated fields
@@ -396,6 +398,38 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
             }
             if (cnew) flags |= LF_CHROM_NEW;
         }
+    }
+    if (hop_skip) {
+        // The hopping index (k_index_hop) never looked at the first hop_skip bytes behind a record's start: a record shorter
+        // than that — fewer sample columns than the header declares, a parse error in htslib — has its newline in there and
+        // arrives merged with its successor.  A KEPT record is read byte by byte by the encoders, which report the newline
+        // (HHGT_ERR_MALFORMED); a record the region / isSNP filter DROPS is read by nobody, and the valid record merged into
+        // it would vanish unreported.  So the dropped records' unexamined bytes are examined here, a wave per record
+        // (rare: nothing is dropped from a 1000G-style SNP file), and a newline in there makes the record malformed too.
+        const uint32_t lane = threadIdx.x & 63u;
+        const bool chk = (flags & LF_RECORD) && !(flags & (LF_KEEP | LF_MALFORMED));
+        unsigned long long todo = __ballot(chk);
+        while (todo != 0ull) {   // (wave-uniform)
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)s, l), ee = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
+            const uint32_t hi = ee - ss < hop_skip ? ee : ss + hop_skip;   // (the index searched from (ss + hop_skip) & ~15 on)
+            uint32_t hit = 0;
+            for (uint32_t x = ss + 16u * lane; x < hi; x += 1024u) {
+                uint32_t d[4] = {0u, 0u, 0u, 0u};
+                if ((uint64_t)x + 16ull <= n) {
+                    const u32x4_unaligned t = *reinterpret_cast<const u32x4_unaligned *>(text + x);
+                    d[0] = t.x, d[1] = t.y, d[2] = t.z, d[3] = t.w;
+                } else {
+                    for (uint32_t k = 0; k < 16u && (uint64_t)x + k < n; ++k) d[k >> 2] |= (uint32_t)text[x + k] << (8u * (k & 3u));
+                }
+                const uint32_t m = nl_mask4(d[0]) | (nl_mask4(d[1]) << 4) | (nl_mask4(d[2]) << 8) | (nl_mask4(d[3]) << 12);
+                hit |= hi - x >= 16u ? m : (m & ((1u << (hi - x)) - 1u));
+            }
+            if (__ballot(hit != 0u) != 0ull && (int)lane == l) flags = (flags & LF_CHROM_NEW) | LF_RECORD | LF_MALFORMED;
+        }
+    }
+    if (i < n_lines) {
         l_soff[i] = soff;
         l_lend[i] = e;
         l_pos[i] = pos0;
@@ -482,14 +516,18 @@ __global__ __launch_bounds__(256) void k_compact_kept(
 }
 
 // ---------------------------------------------------------------------------------------------
+// min_line: no line of this text can be shorter (0 = unknown).  Long lines: the hopping index reads the text behind the
+// bound only (-> the bytes it skips behind every record start; 0: the plain scan); HHGT_INDEX_HOP=0 keeps the plain scan.
+static uint32_t index_hop_skip(uint32_t min_line)
+{
+    static const int hop = getenv("HHGT_INDEX_HOP") ? atoi(getenv("HHGT_INDEX_HOP")) : 1;
+    return hop && min_line >= 1536u ? min_line - 16u : 0u;   // margin: the loads start at the 16-byte line in front of the target
+}
+
 int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
                           uint32_t n_regions, uint32_t min_line, DevCounters *d_cnt, hipStream_t st)
 {
-    // min_line: no line of this text can be shorter (0 = unknown).  Long lines: the hopping index reads the text behind
-    // the bound only; HHGT_INDEX_HOP=0 keeps the plain scan.
-    static const int hop = getenv("HHGT_INDEX_HOP") ? atoi(getenv("HHGT_INDEX_HOP")) : 1;
-    if (hop && min_line >= 1536u) {
-        const uint32_t skip = min_line - 16u;      // margin: the loads start at the 16-byte line in front of the target
+    if (const uint32_t skip = index_hop_skip(min_line)) {
         static const int hop_k = getenv("HHGT_INDEX_HOP_K") ? atoi(getenv("HHGT_INDEX_HOP_K")) : 8;   // development
 #define HOP_LAUNCH(U, K)                                                                                                   \
     hipLaunchKernelGGL((k_index_hop<U, K>), dim3(((n_regions + K - 1) / K + 3) / 4), dim3(256), 0, st, d_text, n, d_slots, d_counts, \
@@ -525,8 +563,10 @@ int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, 
                        uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st)
 {
     if (max_lines == 0) return HHGT_OK;
+    // (the skip the hopping index used on this text, 0 for the plain scan: the same rule as launch_index_newlines)
+    const uint32_t hop_skip = index_hop_skip(S ? 2u * S + 17u : 0u);
     hipLaunchKernelGGL(k_parse_fixed, dim3((max_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, d_nlines,
-                       max_lines, region, S, l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_cnew, d_cnt);
+                       max_lines, region, S, l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_cnew, d_cnt, hop_skip);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
