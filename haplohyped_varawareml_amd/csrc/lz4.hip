@@ -787,7 +787,7 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     if (bitplanes) {
         // effort: candidates tried per one along the hash chain (clevel 1-2: none, offset-1 runs only)
         static const int depth_env = getenv("HHGT_LZ4_DEPTH") ? atoi(getenv("HHGT_LZ4_DEPTH")) : -1;
-        const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 16);
+        const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 12);
         const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, pg, n_chunks * (chunk_nbytes / 8192), d_scratch,
                                             slot_bytes, d_csize, depth, st);
         if (rc != HHGT_OK) return rc;

@@ -801,6 +801,7 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint6
     else if (depth == 2) BP_LAUNCH(2);
     else if (depth <= 4) BP_LAUNCH(4);
     else if (depth <= 8) BP_LAUNCH(8);
+    else if (depth <= 12) BP_LAUNCH(12);
     else BP_LAUNCH(16);
 #undef BP_LAUNCH
 #undef BP_LAUNCH2

@@ -120,7 +120,7 @@ def test_random_planes_match_the_reference(ctx, ref, scale, seed):
         assert planes.size / total > 5.0          # the ratio the byte-wise encoder reaches on such planes is 5.12
 
 
-@pytest.mark.parametrize("clevel,depth", [(1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 16)])
+@pytest.mark.parametrize("clevel,depth", [(1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 12)])
 def test_effort_levels_match_the_reference(ctx, ref, clevel, depth):
     """clevel -> candidates per one along the hash chain; every level byte-identical to the reference at that depth,
     deeper levels no larger"""
@@ -135,7 +135,7 @@ def test_effort_levels_match_the_reference(ctx, ref, clevel, depth):
         want = ref(pl, depth)
         assert np.array_equal(got[k], want), f"clevel {clevel}: plane {k} differs from gapenc_ref(depth={depth})"
     ratio = planes.size / total
-    lo = {0: 3.0, 1: 5.2, 2: 5.5, 4: 5.7, 8: 5.8, 16: 5.85}[depth]
+    lo = {0: 3.1, 1: 5.6, 2: 5.9, 4: 6.1, 8: 6.2, 12: 6.25}[depth]   # (round 3's run / pull-back rules: +8 % at every depth)
     assert ratio > lo, (clevel, ratio)
 
 
