@@ -742,11 +742,18 @@ def main():
     if dom == "lz4":
         # the contract's roofline is HBM or MFMA; this kernel is bound by neither
         sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_lz4_sq.txt")))
-        roof["limiter"] = ("the length of a wave's dependent chain (~220 LDS instructions per plane, most of them round trips, between "
-                           "dependent vector instructions): ~1.7 k vector + 1.0 k scalar + 0.22 k LDS instructions per 4 KiB plane at 7 waves "
-                           "per SIMD (" + (os.path.basename(sq[-1]) if sq else "profiles/") + ", SQ counters from a separate --pmc pass); "
-                           "stage time follows occupancy (12.2 / 13.3 / 14.9 / 17.2 ms at 14 / 13 / 11 / 9 workgroups per CU), not the "
-                           "instruction count; HBM at a sixth of its peak under this kernel")
+        mix = ""
+        try:   # instruction mix per 4 KiB plane from the newest committed SQ-counter pass (a separate rocprofv3 --pmc run)
+            line = next(l for l in open(sq[-1]) if l.startswith("k_lz4_bitplanes<2, true, false>"))
+            w = json.loads(line[line.index("{"):])
+            mix = (f"{w['SQ_INSTS_VALU'] / 1e3:.2f} k vector + {w['SQ_INSTS_SALU'] / 1e3:.2f} k scalar + {w['SQ_INSTS_LDS'] / 1e3:.2f} k LDS "
+                   f"instructions per 4 KiB plane at 7 waves per SIMD ({os.path.basename(sq[-1])}); ")
+        except Exception:
+            pass
+        roof["limiter"] = ("the sum of a wave's DEPENDENT latencies (vector -> vector, ~250 LDS instructions per plane most of them round "
+                           "trips, scalar <-> vector hand-overs, branches): " + mix + "stage time follows occupancy (12.2 / 13.3 / 14.9 / "
+                           "17.2 ms at 14 / 13 / 11 / 9 workgroups per CU) and did not move when 27 % of the scalar instructions were "
+                           "removed or 13 % vector instructions added (DESIGN.md 3.2); HBM at a sixth of its peak under this kernel")
 
     out = {
         "metric": "variants/sec encode+compress, 3M-variant x 2.5k-sample VCF",
