@@ -441,12 +441,12 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
                                                    const uint32_t *__restrict__ k_meta, uint64_t v_base, uint32_t n_kept,
                                                    const LayoutDev &lay, uint8_t *__restrict__ P, int8_t *__restrict__ G,
                                                    uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
-                                                   DevCounters *cnt, uint32_t *img, uint32_t band0)
+                                                   DevCounters *cnt, uint32_t *img, uint32_t tile_v, uint32_t band)
 {
-    const uint64_t gv0 = (v_base / PT_V + blockIdx.x) * (uint64_t)PT_V;   // first global column of the tile
+    const uint64_t gv0 = (v_base / PT_V + tile_v) * (uint64_t)PT_V;   // first global column of the tile
     const long long k0 = (long long)gv0 - (long long)v_base;              // batch-local kept index of it
     if (k0 >= (long long)n_kept || (!lay.ring && gv0 >= lay.v_capacity)) return;
-    const uint32_t s0 = (blockIdx.y + band0) * TILE_S;
+    const uint32_t s0 = band * TILE_S;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t S = lay.S;
@@ -559,16 +559,30 @@ __global__ __launch_bounds__(64 * PT_NW, PT_WGS) void k_encode_planes(const uint
                                                           const uint64_t *__restrict__ d_cursor, LayoutDev lay,
                                                           uint8_t *__restrict__ P, int8_t *__restrict__ G,
                                                           uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag,
-                                                          DevCounters *cnt)
+                                                          DevCounters *cnt, uint32_t tiles_v, uint32_t tiles_s, uint32_t map)
 {
     HHGT_WAVE_PRIO();
     __shared__ __attribute__((aligned(16))) uint32_t img[1024 * PT_ROWDW];   // 32 KiB
     const uint64_t v_base = *d_cursor;
     const uint32_t n_kept = (uint32_t)cnt->n_kept;
-    if (blockIdx.y + 1u == gridDim.y)
-        encode_planes_tile<true>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, 0u);
+    // which tile: (variant tile, sample band) from the linear workgroup id
+    uint32_t tile_v, band;
+    if (map == 0u) {          // variant tile fastest (round 3a's 2-D grid)
+        tile_v = blockIdx.x % tiles_v;
+        band = blockIdx.x / tiles_v;
+    } else if (map == 1u) {   // sample band fastest: workgroups that run together read neighbouring KiB of the same lines
+        band = blockIdx.x % tiles_s;
+        tile_v = blockIdx.x / tiles_s;
+    } else {                  // ... and the bands of one variant tile stay on one XCD (workgroup id mod 8), so the cache lines
+        const uint32_t x = blockIdx.x & 7u, q = blockIdx.x >> 3;   // two neighbouring bands share are fetched by one L2
+        band = q % tiles_s;
+        tile_v = (q / tiles_s) * 8u + x;
+    }
+    if (tile_v >= tiles_v) return;
+    if (band + 1u == tiles_s)
+        encode_planes_tile<true>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, tile_v, band);
     else
-        encode_planes_tile<false>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, 0u);
+        encode_planes_tile<false>(text, n, k_soff, k_meta, v_base, n_kept, lay, P, G, redo_list, redo_flag, cnt, img, tile_v, band);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -995,8 +1009,11 @@ int launch_encode_planes(const uint8_t *d_text, uint64_t n, const uint32_t *k_so
     const uint32_t tiles_s = (lay.S + TILE_S - 1) / TILE_S;
     // the append position is only known on the device: one tile more than the lines need covers any phase
     const uint64_t tiles_v = ((uint64_t)(PT_V - 1) + (uint64_t)n_lines_bound + (PT_V - 1)) / PT_V;
-    hipLaunchKernelGGL(k_encode_planes, dim3((uint32_t)tiles_v, tiles_s), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta, d_cursor, lay,
-                       d_P, d_G, redo_list, redo_flag, d_cnt);
+    // measured (tools/dev/enc_map.sh, encode stage of the bench): 7.6 ms variant tile fastest, 7.4 ms band fastest / XCD-aware
+    static const uint32_t map = getenv("HHGT_ENC_MAP") ? (uint32_t)atoi(getenv("HHGT_ENC_MAP")) : 2u;
+    const uint64_t n_wg = map == 2u ? (tiles_v + 7ull) / 8ull * 8ull * tiles_s : tiles_v * tiles_s;
+    hipLaunchKernelGGL(k_encode_planes, dim3((uint32_t)n_wg), dim3(64 * PT_NW), 0, st, d_text, n, k_soff, k_meta, d_cursor, lay,
+                       d_P, d_G, redo_list, redo_flag, d_cnt, (uint32_t)tiles_v, tiles_s, map);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
