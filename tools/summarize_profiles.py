@@ -25,7 +25,7 @@ shutil.copy(find("kernel_stats.csv", tag), f"profiles/{prefix}_bench_kernel_stat
 shutil.copy(os.path.join(src, "bench_line.json"), f"profiles/{prefix}_bench_line.json")
 shutil.copy(os.path.join(src, "bench_line_under_rocprof.json"), f"profiles/{prefix}_bench_line_under_rocprof.json")
 VARIANTS = 300000
-PASSES = 2   # bench.py runs one serial profiling pass + the timed step
+PASSES = None   # passes over the cohort in that command: counted from the launches below (22 shards per pass)
 
 
 def per_kernel(path, counter):
@@ -41,6 +41,9 @@ def per_kernel(path, counter):
 
 f, nf = per_kernel(find("counter_collection.csv", "f_"), "FETCH_SIZE")
 w, _ = per_kernel(find("counter_collection.csv", "w_"), "WRITE_SIZE")
+# one k_parse_fixed launch per shard and pass: bench.py runs a warm serial pass (since round 3c), the serial profiling pass
+# and the timed step
+PASSES = max(nf.get("k_parse_fixed", 0) // 22, 1)
 out = {
     "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh) on `bench.py --variants "
                f"{VARIANTS} --steps 1 --warmup 0 --no-overlap` = {PASSES} passes over {VARIANTS} variants x 2504 samples",
