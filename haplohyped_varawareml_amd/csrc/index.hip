@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
 // k_index_hop<U>: the same index for text whose lines cannot be shorter than `skip` bytes — a record with S sample
 // columns has at least 2 S + 17 bytes in front of its newline, so behind every line start that many bytes need not be
 // looked at.  For the 1000G shape (lines of 4 S + 58 bytes) that is half of the text: the pass reads ~5 KB per variant
-// where k_index_newlines reads 10 KB.  A wave owns HOP_K consecutive regions (128 KiB) and walks them line by line:
+// where k_index_newlines reads 10 KB.  A wave owns HOP_K (<= 64, the launcher's choice: 6) consecutive regions and walks
+// them line by line:
 // from `pos` it loads U KiB (16 B per lane, all loads in flight together), takes the first newline, appends it to the
 // slot list of the region it lies in (same slots / counts layout as k_index_newlines: everything downstream is
 // unchanged), looks at the first byte of the next line ('#' header lines and empty lines are short: no skip behind
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
 // its newline falls into a hop it merges with the next line, and the newline is found where the merged line is read:
 // by the general encoder inside the sample columns of a KEPT record (encode.hip), by k_parse_fixed in the skipped bytes
 // of a record the filters DROP (nobody else reads those) — the same error, one record later.
-template <int U, uint32_t HOP_K>
+template <int U>
 __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ slots,
                                                    uint32_t *__restrict__ counts, uint32_t n_regions, uint32_t skip,
-                                                   DevCounters *cnt)
+                                                   DevCounters *cnt, uint32_t HOP_K)
 {
     HHGT_WAVE_PRIO();
     const uint32_t lane = threadIdx.x & 63u;
@@ -528,16 +529,18 @@ int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, 
                           uint32_t n_regions, uint32_t min_line, DevCounters *d_cnt, hipStream_t st)
 {
     if (const uint32_t skip = index_hop_skip(min_line)) {
-        static const int hop_k = getenv("HHGT_INDEX_HOP_K") ? atoi(getenv("HHGT_INDEX_HOP_K")) : 8;   // development
-#define HOP_LAUNCH(U, K)                                                                                                   \
-    hipLaunchKernelGGL((k_index_hop<U, K>), dim3(((n_regions + K - 1) / K + 3) / 4), dim3(256), 0, st, d_text, n, d_slots, d_counts, \
-                       n_regions, skip, d_cnt)
-        if (min_line >= 4096u) {
-            if (hop_k == 2) HOP_LAUNCH(5, 2u);
-            else if (hop_k == 4) HOP_LAUNCH(5, 4u);
-            else HOP_LAUNCH(5, 8u);
-        } else
-            HOP_LAUNCH(3, 4u);
+        // regions per wave.  Measured on the bench (3 M x 2504, index stage per step): 3.9 ms for 4 .. 7, 4.0-4.1 for 8, 4.3 for 12,
+        // 4.4 for 16 and for "as many as make all waves of the launch resident at once" (11 on chr1) — longer walks per wave
+        // cost more than a second, part-filled round of waves; fewer than 4 and the plain scan up to a range's first newline
+        // (half a line per wave) starts to show
+        static const int hop_k_env = getenv("HHGT_INDEX_HOP_K") ? atoi(getenv("HHGT_INDEX_HOP_K")) : 0;   // development
+        uint32_t K = hop_k_env > 0 ? (uint32_t)hop_k_env : 6u;
+        K = K > 64u ? 64u : K;
+#define HOP_LAUNCH(U)                                                                                                      \
+    hipLaunchKernelGGL((k_index_hop<U>), dim3(((n_regions + K - 1) / K + 3) / 4), dim3(256), 0, st, d_text, n, d_slots, d_counts, \
+                       n_regions, skip, d_cnt, K)
+        if (min_line >= 4096u) HOP_LAUNCH(5);
+        else HOP_LAUNCH(3);
 #undef HOP_LAUNCH
         HIP_TRY(hipGetLastError());
         return HHGT_OK;
