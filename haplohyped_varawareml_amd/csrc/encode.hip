@@ -210,12 +210,8 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 #define PT_NW 4            // waves per workgroup
 #endif
 #define PT_LW (PT_V / PT_NW)   // lines per wave
-#ifndef PT_ALIGNED
-#define PT_ALIGNED 0       // 0: one byte-aligned 16-byte load per lane.  1 (measured, not faster: 0.61 against 0.56 ms per chr1-sized
-#endif                     //    shard): every lane loads the two ALIGNED chunks that hold its 16 bytes (the second is its neighbour's
-                           //    first: an L1 hit) and funnel-shifts when the group is packed
 #ifndef PT_G
-#define PT_G (PT_ALIGNED ? 4 : 8)   // lines per load group (aligned form: two registers quads per line)
+#define PT_G 8             // lines per load group
 #endif
 #ifndef PT_DB
 #define PT_DB 1            // the next group's loads are issued before a group is packed
@@ -227,40 +223,8 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 
 struct PlGroup {
     uint4 raw[PT_G];
-#if PT_ALIGNED
-    uint4 hi[PT_G];    // the aligned chunk behind raw[j]; the line's 16 bytes start at byte mis[j] of (raw[j], hi[j])
-    uint32_t mis[PT_G];
-#endif
     uint32_t lvalid;   // bit j: line j of the group is a kept fixed-width line (wave-uniform)
 };
-
-// bytes [m, m + 16) of the 32 bytes (lo, hi); m is wave-uniform
-__device__ __forceinline__ uint4 pl_funnel(const uint4 lo, const uint4 hi, const uint32_t m)
-{
-    if (m == 0u) return lo;
-    const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const uint32_t sh = m & 3u;
-    uint32_t o[4];
-    switch (m >> 2) {   // (wave-uniform)
-    case 0:
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-        break;
-    case 1:
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 2], d[i + 1], sh);
-        break;
-    case 2:
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 3], d[i + 2], sh);
-        break;
-    default:
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbyte(d[i + 4], d[i + 3], sh);
-        break;
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
 
 // the line table of 32 lines at once: lane j holds soff / meta of line kb + j (meta = 0 beyond the batch), so that a
 // load group needs no scalar loads (the first version paid two dependent s_load round trips in front of every line)
@@ -291,7 +255,8 @@ __device__ __forceinline__ uint4 pl_load_line(const uint8_t *__restrict__ text, 
         // wherever the line's sample columns start; in isolation a wave-load whose lanes are not dword-aligned runs at ~80 % of
         // an aligned one — tools/micro/strided_read.hip.  Two aligned forms were built and measured in round 3, both correct,
         // neither faster: aligned chunks + the neighbour lane's data by wavefront shift (the 65th chunk needs its own load per
-        // line), and two aligned loads per lane with a deferred funnel shift (PT_ALIGNED=1).)
+        // line), and two aligned loads per lane with a deferred funnel shift (0.61 against 0.56 ms per chr1-sized shard;
+        // both in git history: round 3).)
         u32x4_unaligned t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(text + off));
         v = make_uint4(t.x, t.y, t.z, t.w);
     } else {
@@ -334,38 +299,11 @@ __device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__rest
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)stp.meta, j0 + j);
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)stp.soff, j0 + j);
         uint4 v = make_uint4(FILL_FIELD, FILL_FIELD, FILL_FIELD, FILL_FIELD);
-#if PT_ALIGNED
-        uint4 h = v;
-        uint32_t m = 0;
-#endif
         if (meta & LF_FAST) {   // (wave-uniform)
             lv |= 1u << j;
-#if PT_ALIGNED
-            // Not the band of the last sample: behind this band's 1024 bytes the line goes on.  The 16 bytes of a lane start
-            // wherever the line's sample columns start, and a wave-load whose lanes are not dword-aligned runs at ~80 %
-            // (tools/micro/strided_read.hip): every lane loads the aligned chunk that holds its first byte and the one
-            // behind it (its neighbour's first: an L1 hit); the misalignment is the same for all lanes; pl_funnel picks the
-            // bytes when the group is packed, so all loads of a group are in flight before the first is used.
-            const uint64_t off = (uint64_t)soff + 4ull * ls;
-            m = EDGE ? 0u : (soff & 15u);   // (text is 16-byte aligned and 4 * ls a multiple of 16: the same m in every lane)
-            if (!EDGE && m != 0u && (uint64_t)soff + 4ull * (ls & ~255u) - m + 1040ull <= n) {
-                const u32x4_al *pa = reinterpret_cast<const u32x4_al *>(text + (off - m));
-                const u32x4_al c0 = __builtin_nontemporal_load(pa), c1 = __builtin_nontemporal_load(pa + 1);
-                v = make_uint4(c0.x, c0.y, c0.z, c0.w);
-                h = make_uint4(c1.x, c1.y, c1.z, c1.w);
-            } else {
-                m = 0u;
-                v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
-            }
-#else
             v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
-#endif
         }
         gr.raw[j] = v;
-#if PT_ALIGNED
-        gr.hi[j] = h;
-        gr.mis[j] = m;
-#endif
     }
     gr.lvalid = lv;
 }
@@ -388,11 +326,7 @@ __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, u
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, bad = 0;
 #pragma unroll
     for (int j = 0; j < PT_G; ++j) {
-#if PT_ALIGNED
-        const uint4 x = pl_funnel(gr.raw[j], gr.hi[j], gr.mis[j]);
-#else
         const uint4 x = gr.raw[j];
-#endif
         a0 |= (x.x & 0x00010001u) << (sh + j);
         a1 |= (x.y & 0x00010001u) << (sh + j);
         a2 |= (x.z & 0x00010001u) << (sh + j);
@@ -624,7 +558,6 @@ __device__ __forceinline__ uint32_t parse_gt_bytes(RD rd, uint32_t p, uint32_t l
 }
 
 #define GEN_HALO 64u  // bytes staged past each 1 KiB piece: a GT sub-field that starts in the piece ends inside it
-#define GEN_IMG_MAX_S 24576u   // widest cohort whose line image (4 bits per sample) a wave keeps in LDS: 12 KiB
 
 // 16 bytes of the text at `at` if they lie inside it, else what there is (zero-filled): the last line of a text may end
 // within 16 bytes of the buffer's end
@@ -662,12 +595,13 @@ __device__ __forceinline__ uint32_t gen_scan_incl(uint32_t x, uint32_t lane)
 // staged piece, the branch-free {0, 1, .} x {|, /} classification of the tile kernel's second level (anything else:
 // the byte walk of the GT rule, lane by lane), and the round's ONE / EXC bits of both haplotypes are four ballots —
 // the nonzero calls go to the planes as global atomic ors (other lines of the same 32-variant group set their bits in the
-// same dwords).  With img_words != 0 (development, launch_encode_general) the round's bits are four ballots merged into an
-// LDS image of the line instead, which goes to the planes at the end of the line.
+// same dwords).
 // Round 3, after config 4 spent 3.8 of 16 ms here (88 k `GT:DP` lines at 115 GB/s): the first version dealt the BYTES
 // to the lanes and let every lane loop over the columns that start in its 16 (two or three half-empty iterations per
-// piece); this one runs 3.6 ms.  Prefetching the next piece and collecting the atomics per line changed nothing or made
-// it worse: what is left is the rate of sparse device-scope atomics, one per nonzero call, each to its own 32-byte piece.
+// piece); this one runs 3.6 ms, of which 2.8 without any global atomic (~500 instructions per KiB and wave).  Collecting a
+// line's calls in an LDS image (four ballots per round, merged by three lanes) and sending them to the planes at the end of
+// the line was built and measured: 4.3 ms — a burst of sparse device-scope atomics hides worse than a trickle (in git
+// history: round 3).
 template <bool PLANES>
 __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restrict__ text, uint64_t n,
                                                         const uint32_t *__restrict__ k_soff,
@@ -676,7 +610,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                                                         const uint32_t *__restrict__ redo_list,
                                                         const uint64_t *__restrict__ d_cursor,
                                                         LayoutDev lay, int8_t *__restrict__ G, uint8_t *__restrict__ P,
-                                                        DevCounters *cnt, uint32_t img_words)
+                                                        DevCounters *cnt)
 {
     const uint64_t v_base = *d_cursor;
     const PlanesGeom pgeom = planes_geom(lay, 0u);
@@ -687,13 +621,10 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
     const uint32_t S = lay.S;
     __shared__ __attribute__((aligned(16))) uint8_t sbuf[4][1024 + GEN_HALO];   // the piece (plus a halo), per wave
     __shared__ uint16_t slist[4][1024];                                          // where its columns start
-    extern __shared__ __attribute__((aligned(16))) uint32_t gen_img[];   // [4 waves][4 kind-planes][img_words]; img_words = 0: no image
     // (the staged piece is always reached as sbuf[wq][...]: through a pointer variable the reader lambda below lost the LDS
     // address space and every character was a flat_load — 915 global-load instructions per line, 520 us per line)
     const uint32_t wq = threadIdx.x >> 6;
 #define buf (sbuf[wq])
-    const bool use_img = PLANES && img_words != 0u;
-    uint32_t *img = gen_img + (size_t)wq * 4u * img_words;
     uint32_t haploid = 0, malformed = 0, n_other = 0;
     for (uint32_t idx = wave; idx < n_redo; idx += n_waves) {
         const uint32_t k = redo_list[idx];
@@ -709,8 +640,6 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
         const uint32_t pmask = 1u << ((uint32_t)(vin % PL_TILE) & 31u);
         const uint32_t rs = soff - 1u;  // the 9th tab: every sample field is preceded by a tab in [rs, lend)
         uint32_t tabs_before = 0, nl_inside = 0;
-        if (use_img)
-            for (uint32_t w = lane; w < 4u * img_words; w += 64u) img[w] = 0u;
         // software pipeline: the piece in `cur` / `hal` was loaded one iteration ago
         uint4 cur = gen_load16(text, n, (uint64_t)rs + 16u * lane);
         uint4 hal = lane < GEN_HALO / 16u ? gen_load16(text, n, (uint64_t)rs + 1024u + 16u * lane) : make_uint4(0u, 0u, 0u, 0u);
@@ -825,19 +754,8 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                     const uint32_t h0 = hv & 0xFFu, h1 = (hv >> 8) & 0xFFu;
                     // kind-planes of a tile: ONE of haplotype 0, ONE of haplotype 1, EXC of haplotype 0, EXC of haplotype 1
                     const bool bk[4] = {act && (h0 == 1u || h0 == 0xF7u), act && (h1 == 1u || h1 == 0xF7u), act && h0 > 1u, act && h1 > 1u};
-                    if (use_img) {
-                        // lane l of the round is sample s_r + l: a ballot is 64 consecutive samples of one kind-plane
-                        const uint32_t s_r = tabs_before + r0, w0 = s_r >> 5, sh = s_r & 31u;
-#pragma unroll
-                        for (int kp = 0; kp < 4; ++kp) {
-                            const unsigned long long B = __builtin_amdgcn_ballot_w64(bk[kp]);
-                            if (B != 0ull) {   // (wave-uniform)
-                                const unsigned long long lo = B << sh, hi = sh ? B >> (64u - sh) : 0ull;
-                                const uint32_t part = lane == 0u ? (uint32_t)lo : (lane == 1u ? (uint32_t)(lo >> 32) : (uint32_t)hi);
-                                if (lane < 3u && w0 + lane < img_words) img[(uint32_t)kp * img_words + w0 + lane] |= part;
-                            }
-                        }
-                    } else {
+#ifndef GEN_NO_SCATTER   // (development: timing of the column rounds alone; invalid planes)
+                    {
                         // (pline: the line's tile and bit are the same for every sample — wave-uniform, computed once per line)
                         uint32_t *pw = reinterpret_cast<uint32_t *>(pline + (uint64_t)s * 32ull);
                         if (bk[0]) atomicOr(pw, pmask);
@@ -845,6 +763,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                         if (bk[2]) atomicOr(pw + 2ull * kstride, pmask);
                         if (bk[3]) atomicOr(pw + 3ull * kstride, pmask);
                     }
+#endif
                     if (bk[2] && h0 != 0xF7u) {
                         ++n_other;
                         if (G) G[g_off()] = (int8_t)h0;
@@ -859,23 +778,6 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
             cur = nx;
             hal = nh;
         }
-#ifndef GEN_NO_SCATTER   // (development: timing of the column rounds alone; invalid planes)
-        if (use_img) {
-            // the line's calls go to the planes: lane l owns samples [32 w, 32 w + 32) for w = l, l + 64, ...; one global
-            // atomic per set bit (other lines of the same 32-variant group may be setting theirs in the same dwords)
-            for (uint32_t kp = 0; kp < 4u; ++kp) {
-                for (uint32_t w = lane; w < img_words; w += 64u) {
-                    uint32_t bits = img[kp * img_words + w];
-                    while (bits) {
-                        const uint32_t b = (uint32_t)__ffs(bits) - 1u;
-                        bits &= bits - 1u;
-                        uint32_t *pw = reinterpret_cast<uint32_t *>(pline + (uint64_t)(32u * w + b) * 32ull);
-                        atomicOr(pw + (uint64_t)kp * kstride, pmask);
-                    }
-                }
-            }
-        }
-#endif
         // fewer sample columns than the header declares; or a line end inside the line: a line shorter than any record
         // with S samples can be (its newline lay in the part the hopping index does not look at, index.hip)
         const bool broken = __builtin_amdgcn_ballot_w64(nl_inside != 0u) != 0ull;
@@ -985,18 +887,12 @@ int launch_encode_general(const uint8_t *d_text, uint64_t n, const uint32_t *k_s
                           int8_t *d_G, uint8_t *d_P, DevCounters *d_cnt, int n_cu, hipStream_t st)
 {
     if (lay.S == 0) return HHGT_OK;
-    // HHGT_GEN_IMG=1: every wave keeps the calls of its line in an LDS image (4 bits per sample, merged from ballots) and sends
-    // them to the planes at the end of the line.  Measured on config 4: 4.3 ms against 3.6 ms with the atomics issued from
-    // the column rounds — the ~70 M sparse device-scope atomics per pass (one per nonzero call, each to its own 32-byte
-    // piece) are what this kernel waits for either way, and a burst of them at the end of a line hides worse.  Off by default.
-    static const bool img_env = getenv("HHGT_GEN_IMG") && atoi(getenv("HHGT_GEN_IMG")) == 1;
-    const uint32_t img_words = d_P && img_env && lay.S <= GEN_IMG_MAX_S ? (lay.S + 31u) / 32u : 0u;
     if (d_P)
-        hipLaunchKernelGGL(k_encode_general<true>, dim3((uint32_t)n_cu * 8u), dim3(256), (size_t)img_words * 64u, st, d_text, n, k_soff,
-                           k_lend, k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt, img_words);
+        hipLaunchKernelGGL(k_encode_general<true>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
+                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt);
     else
         hipLaunchKernelGGL(k_encode_general<false>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, d_text, n, k_soff, k_lend,
-                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt, 0u);
+                           k_meta, redo_list, d_cursor, lay, d_G, d_P, d_cnt);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
