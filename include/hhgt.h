@@ -183,9 +183,10 @@ int hhgt_pad_tail_cursor(hhgt_ctx *ctx, const hhgt_layout *lay, const uint64_t *
  * ------------------------------------------------------------------------------------------- */
 uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize);
 /* Blosc clevel analogue (the reference passes clevel 5: compression_opts[4], vcf_to_h5.py:135) = search effort, candidates
- * tried per position: 1..2: none (offset-1 runs only), 3..4: 1, 5..6: 2 (default 5), 7: 4, 8: 8, 9: 16; on 1000G-shaped
- * planes ratio 5.6 / 5.9 / 6.1 / 6.2 / 6.3 for 1 / 2 / 4 / 8 / 16 at about 0.45 ms more per 3 M x 2504 cohort and
- * candidate.  Every level emits the same LZ4 block format. */
+ * tried per position: 1..2: none (offset-1 runs only), 3..4: 1, 5..6: 2 (default 5), 7: 4, 8: 8, 9: 12; on 1000G-shaped
+ * planes ratio 3.31 / 6.05 / 6.42 / 6.67 / 6.81 / 6.84 for 0 / 1 / 2 / 4 / 8 / 12 at about 0.45 ms more per 3 M x 2504
+ * cohort and candidate (LZ4HC level 5, what the reference's setting selects: 7.01).  Every level emits the same LZ4 block
+ * format. */
 int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
 /* NON-REFERENCE mode (measured separately and labelled so): with on != 0 the record filter also
  * keeps multi-allelic SNP sites — |REF| = 1 and ALT a comma-separated list of single bases from {A,C,G,T} — where the
