@@ -543,6 +543,9 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         const uint32_t gq = q1 - qp1 - 1u;
         uint32_t len = 0, nb = 0, c1 = 0;
         bool hv = false;
+        uint32_t a_last = jj;   // hv: P-index of the last one the match covers
+        uint32_t z_last = 0;    // hv: zeros the match takes behind that one (0: it ends with the one)
+        bool clamped = false;   // hv: the match was cut at the stream's match limit
         if (DEPTH > 0) {
             const uint32_t a4 = bp_gap4(S.gbw, jj);
             const uint8_t *gbb = reinterpret_cast<const uint8_t *>(S.gbw);
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                 const uint32_t cc1 = P[jq], cp1 = P[jq - 1u];
                 uint32_t a = jj + bk, b = jq + bk;          // P-indices of the ones the first open comparison starts at
                 uint32_t pa = P[a], pb = P[b];
-                uint32_t clen = pa - q1, costR = 0, tailz = 0;
+                uint32_t clen = pa - q1, costR = 0, tailz = 0, zl = 0;
 #pragma unroll
                 for (uint32_t s = 0; s < BP_PICK; ++s) {
                     const uint32_t g = (a4 >> (8u * s)) & 0xFFu;
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                     costR += act ? 1u + (ga >= BP_TMIN + 1u ? 4u : ga) : 0u;
                     clen += act ? 1u + (stop ? z : ga) : 0u;
                     tailz = (act & stop) ? ga - z : tailz;
+                    zl = (act & stop) ? z : zl;
                     act = act & !stop;
                     a += act ? 1u : 0u;
                     b += act ? 1u : 0u;
@@ -620,6 +624,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                     cnb = cnb < BP_BACK ? cnb : BP_BACK;
                     const uint32_t costH = 3u + (clen + cnb >= 19u ? 1u : 0u) - cnb + (tailz >= BP_TMIN ? 3u : tailz);
                     uint32_t end = (uint32_t)q + clen;
+                    clamped = end > BP_MATCHLIMIT;
                     end = end < BP_MATCHLIMIT ? end : BP_MATCHLIMIT;
                     // signed compares: costH may go below zero when many zeros are pulled in
                     const int gain = (int)costR - (int)costH;
@@ -627,20 +632,26 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
                     len = hv ? end - (uint32_t)q : 0u;
                     nb = hv ? cnb : 0u;
                     c1 = hv ? cc1 : 0u;
+                    a_last = a;
+                    z_last = zl;
+                    clamped = clamped & hv;
                 }
             }
         }
         BP_MARK("cand_done");
         const uint32_t E = hv ? (uint32_t)q + len : (uint32_t)(q + 1);   // end of what this one codes (0 for the virtual one)
-        // first one at or behind E: ones in front of bit E of the map
-        uint32_t nxt;
-        {
+        // first one at or behind E = the number of ones in front of position E.  A one that codes itself alone (E = q + 1) has
+        // itself and its predecessors in front: its own P-index.  A match ends in the zeros behind the last one it covers (or
+        // exactly at the next one): that one's P-index.  Only a match that was cut at the stream's match limit (a handful of
+        // ones at the very end of a plane) needs the count from the bit map.
+        uint32_t nxt = hv ? a_last : jj;
+        if (__builtin_amdgcn_ballot_w64(clamped) != 0ull) {   // (wave-uniform, rare)
             const uint32_t w = E >> 6, bb = E & 63u, wc = w < 63u ? w : 63u;
             const uint32_t lo = bm[2u * wc], hi = bm[2u * wc + 1u];
             const uint32_t mlo = bb >= 32u ? 0xFFFFFFFFu : ((1u << bb) - 1u);
             const uint32_t mhi = bb > 32u ? ((1u << (bb - 32u)) - 1u) : 0u;
             const uint32_t in_map = (uint32_t)wpre[wc] + (uint32_t)__popc(lo & mlo) + (uint32_t)__popc(hi & mhi);
-            nxt = w >= 64u ? m : in_map;
+            nxt = clamped ? (w >= 64u ? m : in_map) : nxt;
         }
         BP_MARK("nxt_done");
         // ---- which ones of the window are coded: follow nxt from `cur` by pointer doubling.  (Measured against the plain
@@ -681,7 +692,11 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         //      coded one — are queued; layout and emission run on 64 of them at a time (bp_emit_batch), every lane busy,
         //      where the first version laid out and emitted per window with the ~30 % of its lanes that were coded ones
         const bool onM = sel && hv;
-        const uint32_t rs = E + ((E == 0u || ((bp_bits(bm, E ? E - 1u : 0u) & 1u) != 0u)) ? 1u : 0u);
+        // the run behind E starts one later when byte E - 1 is a one (an offset-1 run copies its predecessor): always for a one
+        // that codes itself alone (and the virtual one in front of the stream), for a match when it ends with its last one
+        uint32_t rs = E + ((!hv || z_last == 0u) ? 1u : 0u);
+        if (__builtin_amdgcn_ballot_w64(clamped) != 0ull)   // (wave-uniform, rare: a match cut at the match limit — ask the bit map)
+            rs = clamped ? E + ((bp_bits(bm, E - 1u) & 1u) ? 1u : 0u) : rs;
         uint32_t re = (uint32_t)P[(nxt < m ? nxt : m) + 1u] - 1u;   // position of the next one (n behind the last)
         re = re < BP_MATCHLIMIT ? re : BP_MATCHLIMIT;
         const bool onT = sel && (int)re - (int)rs >= BP_TMIN && rs <= BP_MFLIMIT;   // (long enough; emitted or not: bp_emit_batch)
