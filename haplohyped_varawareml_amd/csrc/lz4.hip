@@ -36,6 +36,13 @@
 #ifndef LZ_MINRUN
 #define LZ_MINRUN 6u
 #endif
+// Bytes behind the end of every stream in LDS that are ZERO: the window encoder's lanes fetch the 24 bytes at positions
+// up to mflimit + 63 = n + 51, i.e. they look at up to 76 bytes past the end of their stream.  Those positions are never
+// coded, but what a lane in front of them measures (how far its hash candidate agrees, whether the offset-1 run or the
+// hash match is the longer one before both are cut at the stream's match limit) decided between two equally valid
+// encodings — and with 8 bytes of slack the second wave of a workgroup was looking at the first wave's live hash table
+// there: streams differed from run to run on a few planes (round 3, tools/dev/planes_diff.py).  Fixed in round 4.
+#define LZ_SLACK 96u
 #ifndef LZ_MINHASH
 #define LZ_MINHASH 6u
 #endif
@@ -740,6 +747,11 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
                 data[(typesize - 1u) * pstride + nelem + (i - body)] = v;  // tail after the last plane
         }
     }
+    {   // LZ_SLACK: what the lanes see behind the end of a stream is zeros, not a neighbour's table or a previous block
+        const uint32_t w_ = threadIdx.x >> 6;
+        if (w_ < nstreams)
+            for (uint32_t k = threadIdx.x & 63u; k < LZ_SLACK; k += 64u) data[(size_t)w_ * pstride + neblock + k] = 0;
+    }
     __syncthreads();
     // ---- phase B: one wave per stream
     if (only_marked && csize[(uint64_t)bid * nwaves + wave] != 0xFFFFFFFFu) {
@@ -795,12 +807,12 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
     const uint32_t nwaves = split ? (uint32_t)typesize : 1u;
     const uint32_t nblocks = (uint32_t)((chunk_nbytes + blocksize - 1) / blocksize);
-    // per-stream LDS stride: stream bytes + slack for the 4-byte lookahead, 16-byte aligned
+    // per-stream LDS stride: stream bytes + LZ_SLACK zero bytes for the lanes' lookahead, 16-byte aligned
     const uint32_t max_stream = split ? (uint32_t)blocksize / (uint32_t)typesize : (uint32_t)blocksize;
-    uint32_t sstride = (max_stream + 8u + 15u) & ~15u;
+    uint32_t sstride = (max_stream + LZ_SLACK + 15u) & ~15u;
     if (split && chunk_nbytes % blocksize) {
         // a leftover block is compressed as ONE stream laid out contiguously over the data area
-        uint32_t need = ((uint32_t)(chunk_nbytes % blocksize) + 8u + 15u) & ~15u;
+        uint32_t need = ((uint32_t)(chunk_nbytes % blocksize) + LZ_SLACK + 15u) & ~15u;
         if (need > sstride * nwaves) sstride = (need + nwaves - 1) / nwaves;
         sstride = (sstride + 15u) & ~15u;
     }
