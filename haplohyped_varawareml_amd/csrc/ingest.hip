@@ -876,16 +876,16 @@ void source_main(hhgt_ingest *g)
 // ---------------------------------------------------------------------------------------------------------------
 // driver thread
 // ---------------------------------------------------------------------------------------------------------------
-bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
+// geometry of an input's ring + every buffer whose size follows from the sample count: the state's own (ring of chunk columns
+// as planes / int8, variant tables, cursor) and the batch slots.  at_open: called from hhgt_ingest_open with the caller's
+// expect_samples, when every slot still sits in its pool — so that the first input finds its buffers made (and pinned).
+static bool size_input_state(hhgt_ingest *g, hhgt_ingest::InState *X, uint64_t S, uint64_t S_file, uint64_t block_bytes, bool at_open)
 {
-    hhgt_ingest::InState *X = &g->ist[g->n_begun++ & 1u];
-    in->state = X;
-    const uint64_t S = in->S;
     const int32_t sc = g->o.sc, vc = g->o.vc;
     // a kept line holds S sample columns of at least two bytes behind nine fixed columns
     // (file inputs: the reader never hands out blocks below 1 MiB and grows a text buffer to what a block needs)
     if (block_bytes < (1ull << 20)) block_bytes = 1ull << 20;
-    X->kept_per_block = block_bytes / (2 * in->S_file + 16) + 2;
+    X->kept_per_block = block_bytes / (2 * S_file + 16) + 2;
     const uint64_t W = X->kept_per_block / (uint64_t)vc + 2;   // chunk columns one block can touch
     X->ring_cols = 2 * W + 6;
     memset(&X->lay, 0, sizeof(X->lay));
@@ -908,15 +908,6 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     G_TRY(X->t_ref.ensure((size_t)X->lay.v_capacity));
     G_TRY(X->t_alt.ensure((size_t)X->lay.v_capacity));
     G_TRY(X->cursor.ensure(8));
-    // sample padding rows (S .. round_up(S, sc)) are never written by the encoder: zeroed once per input for every
-    // ring column (everything else of a column is overwritten, or zeroed by the tail padding, before it is framed)
-    if (gbytes && S % (uint64_t)sc) {
-        if (X->planes) G_TRY(hhgt_pad_tail_planes(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->P.p, g->s_main));
-        else G_TRY(hhgt_pad_tail(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->G.p, g->s_main));
-    }
-    G_HIP(hipMemsetAsync(X->cursor.p, 0, 8, g->s_main));
-    X->done_cols = 0;
-    X->host_cursor = 0;
     // batch buffers.  They may still be in use by batches of the previous input that are on their way out, so when
     // one has to grow (this input has more samples, or is the first) every slot is collected first — the shipper and
     // the consumer give them back as they go — and returned to the pools afterwards.
@@ -927,10 +918,12 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     for (auto &v : g->var) grow = grow || v.start.cap < (size_t)X->kept_per_block * 4 || v.ref.cap < (size_t)X->kept_per_block;
     if (grow) {
         int tmp;
-        for (int i = 0; i < N_DST; ++i)
-            if (!g->free_dst.pop(tmp)) return false;
-        for (int i = 0; i < N_VAR; ++i)
-            if (!g->free_var.pop(tmp)) return false;
+        if (!at_open) {
+            for (int i = 0; i < N_DST; ++i)
+                if (!g->free_dst.pop(tmp)) return false;
+            for (int i = 0; i < N_VAR; ++i)
+                if (!g->free_var.pop(tmp)) return false;
+        }
         for (auto &d : g->dst) {
             G_TRY(d.d.ensure(need_d));
             G_TRY(d.off.ensure(need_off));
@@ -941,9 +934,36 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
             G_TRY(v.ref.ensure((size_t)X->kept_per_block));
             G_TRY(v.alt.ensure((size_t)X->kept_per_block));
         }
-        for (int i = 0; i < N_DST; ++i) g->free_dst.push(i);
-        for (int i = 0; i < N_VAR; ++i) g->free_var.push(i);
+        if (!at_open) {
+            for (int i = 0; i < N_DST; ++i) g->free_dst.push(i);
+            for (int i = 0; i < N_VAR; ++i) g->free_var.push(i);
+        }
     }
+    if (at_open) {
+        // the shipper's pinned copies of the framed chunks: a batch is at most need_d bytes and about a fifth of that on
+        // genotype planes — a slot that turns out too small still grows where it is used
+        for (auto &o : g->out) G_TRY(o.h.ensure(need_d / 4 + 4096));
+    }
+    return true;
+}
+
+bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
+{
+    hhgt_ingest::InState *X = &g->ist[g->n_begun++ & 1u];
+    in->state = X;
+    const uint64_t S = in->S;
+    if (!size_input_state(g, X, S, in->S_file, block_bytes, false)) return false;
+    const uint64_t gbytes = hhgt_layout_bytes(&X->lay);
+    const int32_t sc = g->o.sc;
+    // sample padding rows (S .. round_up(S, sc)) are never written by the encoder: zeroed once per input for every
+    // ring column (everything else of a column is overwritten, or zeroed by the tail padding, before it is framed)
+    if (gbytes && S % (uint64_t)sc) {
+        if (X->planes) G_TRY(hhgt_pad_tail_planes(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->P.p, g->s_main));
+        else G_TRY(hhgt_pad_tail(g->ctx, &X->lay, X->lay.v_capacity, 0, X->ring_cols, X->G.p, g->s_main));
+    }
+    G_HIP(hipMemsetAsync(X->cursor.p, 0, 8, g->s_main));
+    X->done_cols = 0;
+    X->host_cursor = 0;
     in->t_first = now_s();
     in->header_sent = false;   // announced by the first harvest of this input: behind the previous input's last events
     return true;
@@ -1343,6 +1363,24 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
     if (rc != HHGT_OK) {
         hhgt_ingest_close(g);
         return rc;
+    }
+    if (g->o.expect_samples > 0) {
+        // the caller knows the cohort's width: everything whose size follows from it is made (and pinned) now instead of
+        // inside the first input — both ring states, the batch slots, the shipper's pinned copies, and for the device
+        // inflater the pinned staging of a block's compressed members
+        const uint64_t S = g->o.sites_only ? 0ull : (uint64_t)g->o.expect_samples;
+        bool ok = size_input_state(g, &g->ist[0], S, (uint64_t)g->o.expect_samples, bb + 256, true) &&
+                  size_input_state(g, &g->ist[1], S, (uint64_t)g->o.expect_samples, bb + 256, true);
+        if (ok && dev) {
+            const uint64_t want = (uint64_t)((double)bb_dev / 24.0 * 1.15) + (256u << 10);
+            const size_t tab_room = (size_t)(want / 26 + 2) * 28 + 64;
+            for (auto &sg : g->stg) ok = ok && sg.h.ensure((size_t)want + 64 + tab_room) == HHGT_OK;
+        }
+        if (ok && g->o.device_inflate != 1) hhgt_reader_prewarm(bb_host, 6 * ((g->o.files_ahead > 0 ? g->o.files_ahead : 1) + 1));
+        if (!ok) {
+            hhgt_ingest_close(g);
+            return HHGT_ERR_HIP;
+        }
     }
     g->tm.t_open = now_s();
     g->th_source = std::thread(source_main, g);

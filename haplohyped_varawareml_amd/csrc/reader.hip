@@ -130,6 +130,28 @@ extern "C" void hhgt_reader_trim_pool(void)
     g_pool.clear();
 }
 
+extern "C" int hhgt_reader_prewarm(uint64_t block_bytes, int n_blocks)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
+    if (n_blocks > POOL_MAX_BLOCKS) n_blocks = POOL_MAX_BLOCKS;
+    int have = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto &e : g_pool) have += e.first == (size_t)block_bytes ? 1 : 0;
+    }
+    while (have < n_blocks) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, (size_t)block_bytes, hipHostMallocDefault) != hipSuccess) break;
+        if (!pool_give((size_t)block_bytes, p)) {
+            hipHostFree(p);
+            break;
+        }
+        ++have;
+    }
+    return have;
+}
+
 // CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool
 // shows 256 hardware threads and grants 16 CPUs' worth of time: 96 inflate threads on it only fight each other)
 extern "C" int hhgt_effective_cpus(void)

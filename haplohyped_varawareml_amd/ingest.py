@@ -16,7 +16,7 @@ EV_END, EV_HEADER, EV_VARIANTS, EV_COLUMNS, EV_INPUT_END = 0, 1, 2, 3, 4
 class IngestOpts(C.Structure):
     _fields_ = [("sc", C.c_int32), ("vc", C.c_int32), ("typesize", C.c_int32), ("blocksize", C.c_int32),
                 ("format", C.c_int32), ("sites_only", C.c_int32), ("device_inflate", C.c_int32), ("n_threads", C.c_int32),
-                ("block_bytes", C.c_uint64), ("files_ahead", C.c_int32), ("reserved", C.c_int32)]
+                ("block_bytes", C.c_uint64), ("files_ahead", C.c_int32), ("expect_samples", C.c_int32)]
 
 
 class IngestStats(C.Structure):
@@ -70,17 +70,36 @@ def _view(ptr, n, dtype):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n) * np.dtype(dtype).itemsize,)).view(dtype)
 
 
+def normalize_device_inflate(device_inflate):
+    """-> False | True | "auto" from what callers and HHGT_DEVICE_INFLATE may say: booleans, 0 / 1, "auto", and the strings
+    "0" / "false" / "no" / "off" / "host" / "" (host reader) and "1" / "true" / "yes" / "on" / "device".  Anything else is an
+    error: `bool("host")` is True, and a misspelt policy must not silently pick the device inflater."""
+    if isinstance(device_inflate, str):
+        v = device_inflate.strip().lower()
+        if v == "auto":
+            return "auto"
+        if v in ("", "0", "false", "no", "off", "host"):
+            return False
+        if v in ("1", "true", "yes", "on", "device"):
+            return True
+        raise ValueError(f"device_inflate={device_inflate!r}: expected a boolean, 'auto', 'host' or 'device'")
+    return bool(device_inflate)
+
+
 class Ingest:
     """One engine per (context, chunk geometry).  The context must not be used for anything else while the engine
     is open (its kernels are driven from the engine's threads)."""
 
     def __init__(self, ctx, sc=64, vc=8192, fmt=BLOSC2, sites_only=False, device_inflate=False, n_threads=0,
-                 block_bytes=0, files_ahead=1, typesize=2, blocksize=0):
+                 block_bytes=0, files_ahead=1, typesize=2, blocksize=0, expect_samples=0):
+        """expect_samples > 0: the sample count of the inputs to come — the engine then makes and pins its buffers at open
+        instead of inside the first input (include/hhgt_ingest.h)"""
         self.L = _L()
         self.ctx = ctx
+        device_inflate = normalize_device_inflate(device_inflate)
         o = IngestOpts(int(sc), int(vc), int(typesize), int(blocksize), int(fmt), int(bool(sites_only)),
-                       (2 if device_inflate == "auto" else int(bool(device_inflate))), int(n_threads or 0), int(block_bytes or 0),
-                       int(files_ahead), 0)
+                       (2 if device_inflate == "auto" else int(device_inflate)), int(n_threads or 0), int(block_bytes or 0),
+                       int(files_ahead), int(expect_samples or 0))
         h = C.c_void_p()
         check(self.L.hhgt_ingest_open(ctx.h, C.byref(o), C.byref(h)))
         self.h = h

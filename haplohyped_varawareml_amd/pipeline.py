@@ -222,20 +222,42 @@ class RawColumns:
 
 def _want_device_inflate(device_inflate):
     """False: the host reader inflates (the north star's design, always selectable); True: BGZF files are inflated on the
-    device; "auto" (the default; HHGT_DEVICE_INFLATE=0|1|auto overrides): BGZF files that compress at least 2:1 take the
-    device — their compressed members are the smaller load for the host-device link, which bounds the host path at cohort
-    widths — everything else the host reader (include/hhgt_ingest.h)"""
+    device; "auto" (the default since round 3; HHGT_DEVICE_INFLATE=0|1|auto overrides): in the ENGINE (stream_files, the
+    converter: include/hhgt_ingest.h) BGZF files whose first member inflates to at least twice its size take the device —
+    their compressed members are the smaller load for the host-device link, which bounds the host path at cohort widths —
+    everything else the host reader; in the single-file loop stream_file "auto" means every BGZF file unless the caller's
+    text blocks are below 5 MiB (too few members per launch for the device inflater).  Strings are normalised by
+    ingest.normalize_device_inflate (unknown ones raise)."""
+    from .ingest import normalize_device_inflate
     if device_inflate is None:
         device_inflate = os.environ.get("HHGT_DEVICE_INFLATE", "auto")
-    if isinstance(device_inflate, str):
-        v = device_inflate.strip().lower()
-        return "auto" if v == "auto" else v not in ("", "0", "false", "no", "host")
-    return bool(device_inflate)
+    return normalize_device_inflate(device_inflate)
+
+
+def peek_sample_count(path, limit=64 << 20):
+    """number of sample columns of a .vcf / .vcf.gz file from its #CHROM line (the first `limit` bytes of text at most), or
+    0 when it cannot be told cheaply — what hhgt_ingest_opts.expect_samples wants to hear before the engine opens"""
+    import gzip
+    try:
+        with open(path, "rb") as f:
+            magic = f.read(2)
+        op = gzip.open if magic == b"\x1f\x8b" else open
+        got = 0
+        with op(path, "rb") as f:
+            for line in f:
+                got += len(line)
+                if line.startswith(b"#CHROM"):
+                    return max(len(line.rstrip(b"\r\n").split(b"\t")) - 9, 0)
+                if not line.startswith(b"#") or got > limit:
+                    return 0
+    except OSError:
+        return 0
+    return 0
 
 
 def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=None, n_threads=0, sites_only=False,
                  fmt=dev.BLOSC2, device_inflate=None, on_header=None, on_variants=None, on_columns=None, on_end=None,
-                 files_ahead=1):
+                 files_ahead=1, expect_samples=None):
     """Several inputs through ONE native ingest engine (csrc/ingest.hip): the inflate of the next file overlaps the
     encode of the current one, and nothing waits on the host between blocks.
     jobs: [(path_or_host_buffer, region)]; callbacks get the job index first:
@@ -244,8 +266,11 @@ def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=No
     -> [FileStats] in job order"""
     from .ingest import Columns, Header, Ingest, InputEnd, Variants
     stats = [FileStats() for _ in jobs]
+    if expect_samples is None:     # the first file's header says how wide the cohort is: the engine sizes and pins at open
+        first = next((src for src, _ in jobs if isinstance(src, (str, os.PathLike))), None)
+        expect_samples = peek_sample_count(first) if first is not None else 0
     with Ingest(ctx, sc=sc, vc=vc, fmt=fmt, sites_only=sites_only, device_inflate=_want_device_inflate(device_inflate),
-                n_threads=n_threads, block_bytes=block_bytes or 0, files_ahead=files_ahead) as ing:
+                n_threads=n_threads, block_bytes=block_bytes or 0, files_ahead=files_ahead, expect_samples=expect_samples) as ing:
         for src, region in jobs:
             if isinstance(src, (str, os.PathLike)):
                 ing.add_file(src, region)

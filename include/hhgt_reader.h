@@ -50,6 +50,10 @@ int hhgt_effective_cpus(void);
 /* Closed readers keep up to 32 pinned ring blocks for the next hhgt_reader_open (pinning memory is slow and a
  * converter opens one reader per chromosome file); this frees them. */
 void hhgt_reader_trim_pool(void);
+/* ... and this puts up to n_blocks pinned blocks of block_bytes there ahead of time (the ingest engine does, when its caller
+ * names the sample count at hhgt_ingest_open: the first file then finds its ring pinned).  Returns how many the pool holds
+ * of that size afterwards; without a HIP device nothing is made. */
+int hhgt_reader_prewarm(uint64_t block_bytes, int n_blocks);
 
 /* CRC-32 (RFC 1952) of a host buffer: the carry-less-multiply folding form where the CPU has PCLMULQDQ (what the
  * reader checks every BGZF member with), the 16-byte table form elsewhere. */

@@ -171,3 +171,26 @@ def test_bgzf_crc_mismatch_is_reported(tmp_path):
         with rd.VcfReader(p, block_bytes=1 << 20, n_threads=4) as r:
             for _ in r:
                 pass
+
+
+def test_peek_sample_count(tmp_path):
+    """pipeline.peek_sample_count: the #CHROM line of a plain or gzip / BGZF file -> number of sample columns (what the ingest
+    engine is told as expect_samples before it opens)"""
+    import gzip
+    from haplohyped_varawareml_amd.pipeline import peek_sample_count
+    hdr = b"##fileformat=VCFv4.2\n##contig=<ID=chr1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + \
+        b"\t".join(b"s%d" % i for i in range(37)) + b"\nchr1\t5\t.\tA\tC\t.\t.\t.\tGT\t" + b"\t".join([b"0|1"] * 37) + b"\n"
+    p = tmp_path / "a.vcf"
+    p.write_bytes(hdr)
+    assert peek_sample_count(str(p)) == 37
+    q = tmp_path / "a.vcf.gz"
+    with gzip.open(q, "wb") as f:
+        f.write(hdr)
+    assert peek_sample_count(str(q)) == 37
+    sites = tmp_path / "sites.vcf"
+    sites.write_bytes(b"##x\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\nchr1\t5\t.\tA\tC\t.\t.\t.\n")
+    assert peek_sample_count(str(sites)) == 0
+    assert peek_sample_count(str(tmp_path / "missing.vcf")) == 0
+    nohdr = tmp_path / "n.vcf"
+    nohdr.write_bytes(b"chr1\t5\t.\tA\tC\t.\t.\t.\n")
+    assert peek_sample_count(str(nohdr)) == 0
