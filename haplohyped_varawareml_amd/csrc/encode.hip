@@ -695,6 +695,11 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
                     mm &= mm - 1u;
                 }
             }
+            // the lanes hand the staged piece and the column list to each other through LDS: the LDS executes a wave's
+            // accesses in order, and these two lines keep the COMPILER from moving a lane's read of another lane's slot in
+            // front of the stores above (no instruction is emitted; lz4bits.hip's BP_FENCE is the same pair)
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
             for (uint32_t r0 = 0; r0 < nf; r0 += 64u) {   // (wave-uniform trip count)
                 const uint32_t i = r0 + lane;
                 const uint32_t s = tabs_before + i;
@@ -777,6 +782,8 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
             tabs_before += nf;
             cur = nx;
             hal = nh;
+            __builtin_amdgcn_wave_barrier();   // ... and the next piece's stores behind this piece's reads
+            asm volatile("" ::: "memory");
         }
         // fewer sample columns than the header declares; or a line end inside the line: a line shorter than any record
         // with S samples can be (its newline lay in the part the hopping index does not look at, index.hip)

@@ -40,6 +40,16 @@ def reduce_job(dist, seconds, units, device=None):
     return float(t.item()), float(u.item())
 
 
+def gather_objects(dist, obj):
+    """every rank's `obj` on every rank, in rank order ([obj] without a process group): what makes an N-GPU line say which
+    rank was the slow one (the reductions above only keep max and sum)"""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # host cores of one node, dealt to the ranks (SURVEY.md §8e: "NUMA-pin the inflate threads to the GPU's socket").
 # N ranks that each start `all CPUs` reader threads oversubscribe the host N times — and the host inflate is exactly
@@ -121,18 +131,22 @@ def effective_cpus():
         return max(len(os.sched_getaffinity(0)), 1)
 
 
-def pin_rank(rank, world, device=None, cores=None):
+def pin_rank(rank, world, device=None, cores=None, devices=None):
     """Pins the calling process to its share of the host CPUs (see partition_cpus) and returns
     dict(cpus, n_threads, numa_node, granted).  The thread budget of a rank is its share of what the host GRANTS
     (effective_cpus() // world), never more than its pinned CPUs, and never more than cores // world when the caller
-    names a total (the reference's --cores).  World 1: the affinity is left alone."""
+    names a total (the reference's --cores).  World 1: the affinity is left alone.
+    devices[r] = GPU index of rank r (default: rank r drives GPU r; ranks sharing GPUs — rehearsals, more workers than
+    devices — name theirs, e.g. [r % n_dev for r in range(world)])."""
     allowed = sorted(os.sched_getaffinity(0))
     granted = min(effective_cpus(), len(allowed))
     node = gpu_numa_node(device) if device is not None else None
     if world <= 1:
         n = granted if not cores else max(1, min(int(cores), granted))
         return dict(cpus=allowed, n_threads=n, numa_node=node, granted=granted)
-    nodes = [gpu_numa_node(r) if device is not None else None for r in range(world)]
+    if devices is None:
+        devices = list(range(world))
+    nodes = [gpu_numa_node(devices[r]) if device is not None and r < len(devices) else None for r in range(world)]
     cpus = partition_cpus(allowed, world, rank, nodes, node_cpus)
     try:
         os.sched_setaffinity(0, cpus)

@@ -104,13 +104,22 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
     from .device import DEFAULT_SC, DEFAULT_VC
     from .store import StoreWriter
     stream_fn = stream_fn or _default_stream()
+    real_device = make_ctx is None      # (decided before the default is filled in: a test's fake context has no GPU to ask)
     if make_ctx is None:
         from .device import Context
         make_ctx = Context
     # this rank's share of the host: its reader threads (the engine starts `n_threads` per open file) stay on the CPUs of
     # its GPU's NUMA node and the N ranks of a node do not oversubscribe it (N x --cores threads before)
     from .sharding import pin_rank
-    host = pin_rank(rank, world, device if make_ctx is None or world > 1 else None, conv.cores)
+    devices = None
+    if real_device:
+        try:
+            import torch
+            n_dev = max(torch.cuda.device_count(), 1)
+            devices = [r % n_dev for r in range(world)]      # worker_entry's rule: rank r drives GPU r % n_dev
+        except Exception:
+            devices = None
+    host = pin_rank(rank, world, device if real_device else None, conv.cores, devices=devices)
     ctx = make_ctx(device)
     writer = StoreWriter(part_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=conv.cohort_name,
                          donor_ids=[d for d in conv.donor_ids if d], chunk_format="blosc1")

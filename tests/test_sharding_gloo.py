@@ -32,8 +32,7 @@ def _worker(rank, world, port, q):
     units = sum(sizes[i] for i in mine)
     dist.barrier()
     t, u = sharding.reduce_job(dist, 1.0 + rank, units)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
+    gathered = sharding.gather_objects(dist, mine)          # what bench.py's per_rank array is built with
     q.put((rank, mine, seed_off, wk, wseed, t, u, gathered))
     dist.barrier()
     dist.destroy_process_group()
@@ -70,4 +69,28 @@ def test_lpt_eight_gpus():
         a = sharding.lpt_assign(sizes, n)
         assert sorted(i for x in a for i in x) == list(range(22))
         loads = [sum(sizes[i] for i in x) for x in a]
-        assert max(loads) / (sum(loads) / n) < 1.10
+        # <= 1.05 at the GPU counts the scaling bench runs (2: 1.0002, 4: 1.029, 8: 1.043): under the point where SURVEY 8e's
+        # variant-range split of chr1-chr8 would be worth its second pass over the big files' headers
+        assert max(loads) / (sum(loads) / n) <= 1.05
+    for n in (3, 5, 6, 7):
+        a = sharding.lpt_assign(sizes, n)
+        loads = [sum(sizes[i] for i in x) for x in a]
+        assert max(loads) / (sum(loads) / n) <= 1.10
+
+
+def test_gather_objects_without_a_group():
+    from haplohyped_varawareml_amd import sharding
+    assert sharding.gather_objects(None, {"rank": 0}) == [{"rank": 0}]
+
+
+def test_pin_rank_takes_the_rank_to_device_list(monkeypatch):
+    """ranks sharing GPUs (rehearsals, more workers than devices): the NUMA node asked for is the node of the rank's DEVICE"""
+    from haplohyped_varawareml_amd import sharding
+    asked = []
+    monkeypatch.setattr(sharding, "gpu_numa_node", lambda d: asked.append(d) or 0)
+    monkeypatch.setattr(sharding, "node_cpus", lambda n: sorted(__import__("os").sched_getaffinity(0)))
+    monkeypatch.setattr(__import__("os"), "sched_setaffinity", lambda pid, cpus: None)
+    monkeypatch.setattr(sharding, "effective_cpus", lambda: 8)
+    r = sharding.pin_rank(3, 4, device=1, devices=[0, 1, 0, 1])
+    assert asked[0] == 1 and asked[1:] == [0, 1, 0, 1]
+    assert r["n_threads"] >= 1
