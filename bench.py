@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--no-check", action="store_true", help="skip the correctness gate")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C4 legs")
     ap.add_argument("--only-config", default="", help="development: run only this config leg (C2 or C4[:variants]) and print it")
+    ap.add_argument("--frame-stream", action="store_true",
+                    help="development: the framing half of a compress call on a third stream (hhgt_set_frame_stream); measured "
+                         "in round 4: 22.9 against 22.1 ms per step — not the default")
     ap.add_argument("--lz4-priority", action="store_true", help="development: the compress stream gets the high priority")
     ap.add_argument("--cu-split", default="", help="development: 'E,C' = the encode stream may use the first E CUs of the mask "
                                                    "order, the compress stream the last C (hipExtStreamCreateWithCUMask)")
@@ -166,18 +169,21 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
     """encode + pad + compress of every shard, queued without any host wait (asynchronous chain: the append position
     and every count stay on the device).  With two streams the (issue-bound) LZ4 kernel of shard k overlaps the
     (HBM-bound) index/encode kernels of shard k+1 — the same software pipeline the ingest engine uses; every kernel
-    still runs once per shard per step."""
+    still runs once per shard per step.  (Round 4, measured and removed: odd shards encoded through a second context on a
+    second high-priority stream, so that one shard's small latency-bound kernels run beside the other's HBM-bound encode
+    kernel: 23.6 against 23.1 ms per step; with a lookahead of two 23.6; with the framing on a third stream 22.1.)"""
     import torch
     from haplohyped_varawareml_amd import device as dev
 
     def encode(sh):
+        c = ctx
         sh.cursor.zero_()
         if sh.res.P is not None:
-            ctx.encode_text_planes_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
-            ctx.pad_tail_planes_cursor(sh.res, sh.cursor)
+            c.encode_text_planes_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
+            c.pad_tail_planes_cursor(sh.res, sh.cursor)
         else:
-            ctx.encode_text_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
-            ctx.pad_tail_cursor(sh.res, sh.cursor)
+            c.encode_text_async(sh.text, S, sh.res, sh.cursor, max_lines=sh.max_lines, region=sh.contig, pending=sh.pending)
+            c.pad_tail_cursor(sh.res, sh.cursor)
 
     def compress(sh):
         if sh.res.P is not None:
@@ -191,7 +197,9 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
             encode(sh)
             compress(sh)
         return
-    s_enc, s_cmp = streams
+    s_enc, s_cmp = streams[:2]
+    # frame stream (hhgt_set_frame_stream): the chunks are complete in ITS order
+    s_done = streams[2] if len(streams) > 2 and getattr(ctx, "frame_on", False) else s_cmp
 
     def enc(sh):
         with torch.cuda.stream(s_enc):
@@ -204,7 +212,7 @@ def one_step(ctx, shards, S, blocksize, streams=None, lookahead=1):
         with torch.cuda.stream(s_cmp):
             s_cmp.wait_event(sh.ready)
             compress(sh)
-            sh.cmp_done = s_cmp.record_event()
+            sh.cmp_done = s_done.record_event()
 
     n = len(shards)
     for i in range(min(lookahead, n)):
@@ -426,7 +434,8 @@ def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce
 
         def run(jobs, device_inflate, want_v, passes=2):
             out = []
-            with Ingest(ctx, fmt=fmt, device_inflate=device_inflate, n_threads=n_threads) as ing:
+            # (expect_samples: the engine makes and pins its buffers at open, as pipeline.stream_files does from the first file's header)
+            with Ingest(ctx, fmt=fmt, device_inflate=device_inflate, n_threads=n_threads, expect_samples=S) as ing:
                 for _ in range(passes):
                     sync_all()
                     t = time.perf_counter()
@@ -446,13 +455,17 @@ def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce
                     if kept != want_v:
                         raise AssertionError(f"ingest leg kept {kept} of {want_v} records")
                     dt_max, kept_all = agg(dt, kept)
-                    out.append((dt_max, kept_all, framed))
+                    out.append((dt_max, kept_all, framed, sharding.gather_objects(dist, round(dt, 4))))
             return out
 
         def leg(res, text_bytes_all, extra):
-            (t1, v_all, _), (t2, _, framed) = res[0], res[-1]
-            return dict({"value": v_all / t2, "unit": "variants/s", "seconds": t2, "text_GBps": text_bytes_all / t2 / 1e9,
-                         "first_pass": {"value": v_all / t1, "seconds": t1}, "variants": int(v_all)}, **extra)
+            (t1, v_all, _, r1), (t2, _, framed, r2) = res[0], res[-1]
+            d = dict({"value": v_all / t2, "unit": "variants/s", "seconds": t2, "text_GBps": text_bytes_all / t2 / 1e9,
+                      "first_pass": {"value": v_all / t1, "seconds": t1}, "variants": int(v_all)}, **extra)
+            if world > 1:      # which rank was the slow one (value is all ranks' units over the SLOWEST rank's time)
+                d["per_rank_seconds"] = r2
+                d["first_pass"]["per_rank_seconds"] = r1
+            return d
 
         _, fed_bytes_all = agg(0.0, sum(sh.nbytes for sh in fed))
         _, e2e_bytes_all = agg(0.0, sum(sh.nbytes for sh in pick))
@@ -620,7 +633,7 @@ def main():
     torch.cuda.set_device(local_rank)
     # this rank's share of the host (N > 1: pinned to the CPUs of its GPU's NUMA node, divided among the ranks; the engine's
     # reader threads inherit the mask and get host["n_threads"] of them)
-    host = sharding.pin_rank(rank, world, local_rank)
+    host = sharding.pin_rank(rank, world, local_rank, devices=[r % n_dev for r in range(world)])
     ctx = dev.Context(local_rank)
     ctx.set_clevel(args.clevel)
     if args.only_config:
@@ -651,9 +664,22 @@ def main():
         # the encode chain of the next shard finds free slots (include/hhgt.h hhgt_stream_create; HHGT_COMPRESS_CUS=0
         # gives the compress stream the whole chip)
         streams = (ctx.create_stream("encode"), ctx.create_stream("compress"))
+        if args.frame_stream:
+            # ... and the framing half of a compress call on a third stream, beside the LZ4 kernels of the next shard
+            # (include/hhgt.h hhgt_set_frame_stream): the compress stream's critical path is the LZ4 kernels alone
+            streams += (ctx.create_stream("frame"),)
+
+    def frame_stream(on):
+        if streams is not None and len(streams) > 2:
+            torch.cuda.synchronize()
+            ctx.set_frame_stream(streams[2] if on else None)
+            ctx.frame_on = on
+
+    frame_stream(True)
     for _ in range(args.warmup):
         one_step(ctx, shards, S, args.blocksize, streams, args.lookahead)
     barrier()
+    frame_stream(False)
     ctx.profile(True)
     # one un-timed single-stream pass: clean per-stage device times (with two streams the event pairs of the
     # non-dominant stages also contain the time they spend queued behind the other stream's kernels)
@@ -663,18 +689,29 @@ def main():
     one_step(ctx, shards, S, args.blocksize, None)
     torch.cuda.synchronize()
     stages_serial = ctx.profile_read()
+    frame_stream(True)
     barrier()
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(ctx, shards, S, args.blocksize, streams, args.lookahead)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0      # this rank's own steps (per_rank); the job's time is the slowest rank's, behind the barrier
     barrier()
     dt = time.perf_counter() - t0
     stages = ctx.profile_read()
     ctx.profile(False)
+    frame_stream(False)
 
     dev_for_reduce = "cuda" if backend == "nccl" else "cpu"
     dt_max, total_variants = sharding.reduce_job(dist if use_dist else None, dt, my_variants, device=dev_for_reduce)
+    # N > 1: who had what and how long it took — the reduction above keeps only the slowest rank's time
+    per_rank = sharding.gather_objects(dist if use_dist else None, {
+        "rank": rank, "device": local_rank, "shards": [sh.contig for sh in shards], "variants": my_variants,
+        "text_bytes": text_bytes, "ms_per_step": round(dt_own / args.steps * 1e3, 3),
+        "stages_ms_per_step_timed_region": {k: round(v["ms"] / args.steps, 3) for k, v in stages.items()},
+        "reader_threads": host["n_threads"], "numa_node": host["numa_node"], "pinned_cpus": len(host["cpus"]),
+        "cpu_range": f"{min(host['cpus'])}-{max(host['cpus'])}" if host["cpus"] else ""})
 
     failed = None
     check = None
@@ -775,9 +812,11 @@ def main():
                                   + "), no collective"
                                   + (f" ({backend}: {world} ranks on {n_dev} GPU: a rehearsal, not a scaling measurement)" if shared_gpu else ""),
                    "intermediate": "bit planes, 2 bits per allele (include/hhgt.h)" if planes else "int8 matrix",
-                   "streams": 1 if args.no_overlap else 2,
+                   "streams": 1 if args.no_overlap else (3 if streams is not None and len(streams) > 2 else 2),
+                   "frame_stream": bool(streams is not None and len(streams) > 2),
                    "compress_stream": None if args.no_overlap else "CU mask: 3/4 of the chip (hhgt_stream_create)"},
         "roofline": roof,
+        "per_rank": per_rank if world > 1 else None,
         "correctness": check,
         "stages_ms_per_step": {k: v["ms"] for k, v in stages_serial.items()},
         "stages_ms_per_step_timed_region": {k: v["ms"] / args.steps for k, v in stages.items()},

@@ -102,8 +102,10 @@ def load():
     L.hhgt_pad_tail.argtypes = [vp, C.POINTER(Layout), u64, u64, u64, vp, vp]
     L.hhgt_set_clevel.argtypes = [vp, i32]
     L.hhgt_set_keep_multiallelic.argtypes = [vp, i32]
+    L.hhgt_set_index_mode.argtypes = [vp, i32]
     L.hhgt_stream_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.hhgt_stream_destroy.argtypes = [vp, vp]
+    L.hhgt_set_frame_stream.argtypes = [vp, vp]
     L.hhgt_compress_bound.restype = u64
     L.hhgt_compress_bound.argtypes = [u64, u64, i32, i32]
     L.hhgt_compress_chunks.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, u64, vp, C.POINTER(u64), vp]

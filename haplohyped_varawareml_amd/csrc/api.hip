@@ -106,9 +106,14 @@ extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
     DevBuf *bufs[] = {&c->slots, &c->counts, &c->prefix, &c->nl, &c->scan_tmp, &c->l_soff, &c->l_lend, &c->l_pos,
                       &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun, &c->k_soff,
                       &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag, &c->run_first, &c->run_names,
-                      &c->counters, &c->cursor, &c->result, &c->lz_scratch, &c->lz_csize, &c->lz_marked, &c->fr_bsize, &c->fr_csize,
-                      &c->fr_flags, &c->dec_bad, &c->oh_ovl, &c->oh_lut, &c->crc_x2n};
+                      &c->counters, &c->cursor, &c->result, &c->dec_bad, &c->oh_ovl, &c->oh_lut, &c->crc_x2n};
     for (DevBuf *b : bufs) b->release();
+    for (auto &w : c->cw) {
+        DevBuf *wb[] = {&w.lz_scratch, &w.lz_csize, &w.fr_bsize, &w.fr_csize, &w.fr_flags, &w.fr_state};
+        for (DevBuf *b : wb) b->release();
+        if (w.lz_done) hipEventDestroy(w.lz_done);
+        if (w.fr_done) hipEventDestroy(w.fr_done);
+    }
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->h_result_pinned) hipHostFree(c->h_result_pinned);
     for (auto &p : c->pending) {
@@ -345,14 +350,14 @@ static int encode_check_args(hhgt_ctx *c, const void *d_text, uint64_t nbytes, c
 
 // stage 1: newline index of the block -> prefix[n_regions] holds the line count (device).  min_line: a record with S
 // sample columns cannot be shorter than 9 fixed columns and S fields of one byte and a separator each (0: unknown)
-static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, uint32_t min_line,
+static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, uint32_t min_line, uint32_t S,
                               DevCounters *cnt, hipStream_t st)
 {
     TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
     TRY(c->counts.ensure((size_t)n_regions * 4));
     TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
     TRY(c->scan_tmp.ensure(2 * scan_tmp_elems(n_regions) * 4));
-    TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, min_line, cnt, st));
+    TRY(launch_index_newlines(text, nbytes, c->slots.as<uint32_t>(), c->counts.as<uint32_t>(), n_regions, min_line, S, c->index_mode, cnt, st));
     TRY(launch_scan_exclusive_u32_pair(c->counts.as<uint32_t>(), c->prefix.as<uint32_t>(), nullptr, nullptr, n_regions,
                                        c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
     return HHGT_OK;
@@ -385,7 +390,7 @@ static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, 
         TRY(launch_parse_fixed(text, nbytes, c->nl.as<uint32_t>(), d_nlines, max_lines, rf, L.S,
                                c->l_soff.as<uint32_t>(), c->l_lend.as<uint32_t>(), c->l_pos.as<uint32_t>(),
                                c->l_refalt.as<uint32_t>(), c->l_flags.as<uint32_t>(), c->l_keep.as<uint32_t>(),
-                               c->l_cnew.as<uint32_t>(), cnt, st));
+                               c->l_cnew.as<uint32_t>(), c->index_mode, cnt, st));
         TRY(launch_scan_exclusive_u32_pair(c->l_keep.as<uint32_t>(), c->l_kidx.as<uint32_t>(), c->l_cnew.as<uint32_t>(),
                                            c->l_crun.as<uint32_t>(), max_lines, c->scan_tmp.as<uint32_t>(), c->scan_tmp.cap / 4, st));
         TRY(launch_compact_kept(text, nbytes, c->nl.as<uint32_t>(), d_nlines, max_lines, c->l_soff.as<uint32_t>(),
@@ -515,7 +520,7 @@ static int encode_async_impl(hhgt_ctx *c, const void *d_text, uint64_t nbytes, c
     if (nbytes) {
         {
             StageTimer t(c, st, HHGT_STAGE_INDEX);
-            TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, cnt, st));
+            TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, L.S, cnt, st));
             t.stop();
         }
         TRY(encode_stage_rest(c, text, nbytes, n_regions, max_lines, rf, L, d_cursor, d_G, planes ? d_P : nullptr, d_start, d_stop, d_ref,
@@ -612,7 +617,7 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
         // the synchronous form sizes everything by the exact line count: it is read back once (any input, however
         // short its lines, fits), where the asynchronous form takes the caller's bound
         StageTimer t(c, st, HHGT_STAGE_INDEX);
-        TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, cnt, st));
+        TRY(encode_stage_index(c, text, nbytes, n_regions, L.S ? 2u * L.S + 17u : 0u, L.S, cnt, st));
         c->h_counters->n_lines = 0;
         c->h_counters->err_density = 0;
         HIP_TRY(hipMemcpyAsync(&c->h_counters->n_lines, c->prefix.as<uint32_t>() + n_regions, 4,
@@ -764,24 +769,51 @@ static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, P
     size_t slot;
     codec_geometry(chunk_nbytes, typesize, blocksize, &nblocks, &nwaves, &slot);
     const uint64_t n_streams = n_chunks * nblocks * nwaves;
-    TRY(c->lz_scratch.ensure((size_t)n_streams * slot));
-    TRY(c->lz_csize.ensure((size_t)n_streams * 4));
-    TRY(c->fr_bsize.ensure((size_t)n_chunks * nblocks * 4));
-    TRY(c->fr_csize.ensure(((size_t)n_chunks + 1) * 8));
-    TRY(c->fr_flags.ensure((size_t)n_chunks * 4));
+    // With a frame stream the framing of this call runs there, behind the LZ4 kernels, while the caller's stream is free
+    // for the LZ4 kernels of the next call — which write the other workspace set, and wait for the framing that last read it.
+    hipStream_t fst = c->frame_stream ? c->frame_stream : st;
+    hhgt_ctx::CodecWs &w = c->cw[c->frame_stream ? (c->cmp_seq++ & 1u) : 0u];
+    TRY(w.lz_scratch.ensure((size_t)n_streams * slot));
+    TRY(w.lz_csize.ensure((size_t)n_streams * 4));
+    TRY(w.fr_bsize.ensure((size_t)n_chunks * nblocks * 4));
+    TRY(w.fr_csize.ensure(((size_t)n_chunks + 1) * 8));
+    TRY(w.fr_flags.ensure((size_t)n_chunks * 4));
+    {   // k_frame_fused's state words carry the tag of their launch: zeroed when (re)allocated and when the tag wraps
+        const size_t cap0 = w.fr_state.cap;
+        TRY(w.fr_state.ensure(frame_state_bytes(n_chunks)));
+        if (w.fr_state.cap != cap0 || ++w.fr_tag >= (1u << 20)) {
+            HIP_TRY(hipMemsetAsync(w.fr_state.p, 0, w.fr_state.cap, fst));
+            w.fr_tag = 1;
+        }
+    }
+    if (w.fr_pending) {
+        HIP_TRY(hipStreamWaitEvent(st, w.fr_done, 0));
+        w.fr_pending = false;
+    }
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
         TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), pg, n_chunks, chunk_nbytes, typesize,
-                              blocksize, c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(), c->clevel, st));
+                              blocksize, w.lz_scratch.as<uint8_t>(), slot, w.lz_csize.as<uint32_t>(), c->clevel, st));
         t.stop();
     }
+    if (fst != st) {
+        if (!w.lz_done) HIP_TRY(hipEventCreateWithFlags(&w.lz_done, hipEventDisableTiming));
+        if (!w.fr_done) HIP_TRY(hipEventCreateWithFlags(&w.fr_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(w.lz_done, st));
+        HIP_TRY(hipStreamWaitEvent(fst, w.lz_done, 0));
+    }
     {
-        StageTimer t(c, st, HHGT_STAGE_FRAME);
-        TRY(launch_frame(c->lz_scratch.as<uint8_t>(), slot, c->lz_csize.as<uint32_t>(),
+        StageTimer t(c, fst, HHGT_STAGE_FRAME);
+        TRY(launch_frame(w.lz_scratch.as<uint8_t>(), slot, w.lz_csize.as<uint32_t>(),
                          static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), pg, n_chunks, chunk_nbytes, typesize,
-                         blocksize, format, c->fr_bsize.as<uint32_t>(), c->fr_csize.as<uint64_t>(), static_cast<uint8_t *>(d_dst),
-                         dst_cap, d_chunk_off, c->fr_flags.as<uint32_t>(), st));
+                         blocksize, format, w.fr_bsize.as<uint32_t>(), w.fr_csize.as<uint64_t>(), static_cast<uint8_t *>(d_dst),
+                         dst_cap, d_chunk_off, w.fr_flags.as<uint32_t>(), w.fr_state.p, w.fr_tag, fst));
         t.stop();
+    }
+    if (fst != st) {
+        HIP_TRY(hipEventRecord(w.fr_done, fst));
+        w.fr_pending = true;
+        if (total_bytes) HIP_TRY(hipStreamWaitEvent(st, w.fr_done, 0));   // the synchronous form: the caller's stream sees the chunks
     }
     if (total_bytes) {
         uint64_t tot = 0;
@@ -833,13 +865,15 @@ extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)
 
 extern "C" int hhgt_stream_create(hhgt_ctx *c, int kind, void **out)
 {
-    if (!c || !out || (kind != HHGT_STREAM_ENCODE && kind != HHGT_STREAM_COMPRESS)) {
+    if (!c || !out || (kind != HHGT_STREAM_ENCODE && kind != HHGT_STREAM_COMPRESS && kind != HHGT_STREAM_FRAME)) {
         hhgt_set_error("hhgt_stream_create: bad arguments");
         return HHGT_ERR_ARG;
     }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = nullptr;
-    if (kind == HHGT_STREAM_ENCODE) {
+    if (kind == HHGT_STREAM_FRAME) {
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    } else if (kind == HHGT_STREAM_ENCODE) {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
@@ -867,13 +901,35 @@ extern "C" int hhgt_stream_create(hhgt_ctx *c, int kind, void **out)
     return HHGT_OK;
 }
 
+extern "C" int hhgt_set_frame_stream(hhgt_ctx *c, void *stream)
+{
+    if (!c) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    // framings still in flight on the old stream read the workspace sets: let them finish before the roles change
+    if (c->frame_stream) HIP_TRY(hipStreamSynchronize(c->frame_stream));
+    for (auto &w : c->cw) w.fr_pending = false;
+    c->frame_stream = reinterpret_cast<hipStream_t>(stream);
+    return HHGT_OK;
+}
+
 extern "C" int hhgt_stream_destroy(hhgt_ctx *c, void *stream)
 {
     if (!c) return HHGT_ERR_ARG;
     if (stream) {
         HIP_TRY(hipSetDevice(c->device));
+        if (reinterpret_cast<hipStream_t>(stream) == c->frame_stream) TRY(hhgt_set_frame_stream(c, nullptr));
         HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
     }
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_set_index_mode(hhgt_ctx *c, int mode)
+{
+    if (!c || mode < -1 || mode > 2) {
+        hhgt_set_error("index mode must be -1 (default), 0 (scan), 1 (hop) or 2 (walk)");
+        return HHGT_ERR_ARG;
+    }
+    c->index_mode = mode;
     return HHGT_OK;
 }
 

@@ -16,6 +16,22 @@
 #define HHGT_WAVE_PRIO()
 #endif
 
+// wave-wide inclusive sum on DPP row shifts (no LDS round trips)
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t wave_scan_sum_dpp(uint32_t x, uint32_t lane)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 15);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 31) + t0;
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 47) + t1;
+    const uint32_t row = lane >> 4;
+    return x + (row == 0u ? 0u : (row == 1u ? t0 : (row == 2u ? t1 : t2)));
+}
+#endif
+
 // ---- error plumbing -------------------------------------------------------------------------
 void hhgt_set_error(const char *fmt, ...);
 #define HIP_TRY(expr)                                                                      \
@@ -143,7 +159,17 @@ struct hhgt_ctx {
     DevBuf cursor;         // uint64: v_base of the synchronous hhgt_encode_text (the asynchronous form gets the caller's)
     DevBuf result;         // hhgt_encode_result staging of the asynchronous form
     // compress workspaces
-    DevBuf lz_scratch, lz_csize, lz_marked, fr_bsize, fr_csize, fr_flags, dec_bad, oh_ovl, oh_lut, crc_x2n;
+    // two sets: with a frame stream (hhgt_set_frame_stream) the framing of call k reads set k & 1 while the LZ4 kernels of
+    // call k + 1 write the other
+    struct CodecWs {
+        DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, fr_state;
+        uint32_t fr_tag = 0;       // launch tag of k_frame_fused's state words (1 .. 2^20 - 1, then the buffer is zeroed again)
+        hipEvent_t lz_done = nullptr, fr_done = nullptr;
+        bool fr_pending = false;   // fr_done was recorded behind a framing that read this set
+    } cw[2];
+    uint64_t cmp_seq = 0;
+    hipStream_t frame_stream = nullptr;   // hhgt_set_frame_stream; nullptr: the framing follows the LZ4 kernels on their stream
+    DevBuf dec_bad, oh_ovl, oh_lut, crc_x2n;
     bool crc_x2n_ready = false;
     // pinned host mirror for counters
     DevCounters *h_counters = nullptr;
@@ -154,6 +180,7 @@ struct hhgt_ctx {
     std::vector<std::string> run_names_host;
     int clevel = 5;        // Blosc clevel analogue (reference: compression_opts[4] = 5)
     int keep_multi = 0;    // hhgt_set_keep_multiallelic
+    int index_mode = -1;   // hhgt_set_index_mode (< 0: HHGT_INDEX_MODE, default: the walk)
     // profiling
     int profiling = 0;
     double stage_ms[HHGT_N_STAGES] = {0};
@@ -184,7 +211,8 @@ size_t scan_tmp_elems(uint64_t n);
 
 // index.hip
 int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
-                          uint32_t n_regions, uint32_t min_line, DevCounters *d_cnt, hipStream_t st);
+                          uint32_t n_regions, uint32_t min_line, uint32_t S, int mode, DevCounters *d_cnt, hipStream_t st);
+int index_mode_default();
 // Everything after the newline index is sized by a host-side BOUND on the line count (max_lines) and reads the
 // actual count (d_nlines = prefix[n_regions]) and the append position (d_cursor) from device memory, so the chain
 // can be queued without a host round trip (hhgt_encode_text_async).
@@ -193,7 +221,7 @@ int launch_compact_newlines(const uint32_t *d_slots, const uint32_t *d_counts, c
 int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines,
                        uint32_t max_lines, const RegionFilter &region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
                        uint32_t *l_pos, uint32_t *l_refalt, uint32_t *l_flags, uint32_t *l_keep,
-                       uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st);
+                       uint32_t *l_cnew, int mode, DevCounters *d_cnt, hipStream_t st);
 int launch_compact_kept(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines, uint32_t max_lines,
                         const uint32_t *l_soff, const uint32_t *l_lend,
                         const uint32_t *l_pos, const uint32_t *l_refalt, const uint32_t *l_flags,
@@ -234,7 +262,8 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint6
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
                  PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
                  uint32_t *d_bstart, uint64_t *d_chunk_csize, uint8_t *d_dst, uint64_t dst_cap,
-                 uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st);
+                 uint64_t *d_chunk_off, uint32_t *d_chunk_flags, void *d_state, uint32_t tag, hipStream_t st);
+size_t frame_state_bytes(uint64_t n_chunks);   // d_state: zeroed when allocated, then only ever written by the kernel (tagged words)
 int launch_decode(const uint8_t *d_src, const uint64_t *d_chunk_off, uint64_t n_chunks, uint64_t chunk_nbytes,
                   int typesize, int blocksize, uint8_t *d_dst, unsigned long long *d_bad, hipStream_t st);
 int launch_inflate(const uint8_t *d_src, uint64_t src_bytes, const uint64_t *d_comp_off, const uint32_t *d_comp_len,

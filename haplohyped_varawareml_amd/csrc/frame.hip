@@ -13,6 +13,7 @@
 // k_frame_write : one workgroup per block; dword-wide funnel-shift copy of the stream bytes from the
 //                 LZ4 scratch slots to their final (byte-aligned) position.
 #include "common.h"
+#include <stdlib.h>
 
 #define BLOSC_DOSHUFFLE 0x1u
 #define BLOSC_MEMCPYED 0x2u
@@ -111,74 +112,55 @@ __global__ __launch_bounds__(256) void k_scan_u64(const unsigned long long *__re
     if (threadIdx.x == 0) out[n] = carry;
 }
 
-// copy n bytes src -> dst (dst arbitrary alignment, src 4-byte aligned) by one wave, in two phases so that a
-// caller can issue the loads of SEVERAL streams before the first store: the kernel is a latency chain (one wave per
-// block, a few hundred bytes per stream), so memory round trips per wave are what it costs.
+// copy n bytes src -> dst (dst arbitrary alignment, src 16-byte aligned: an LZ4 scratch slot) by one wave, in two phases so that
+// a caller can issue the loads of SEVERAL streams before the first store: the kernel is a latency chain (one wave per block, a
+// few hundred bytes per stream), so memory round trips and instructions per wave are what it costs.  Round 4: 16 bytes per
+// lane — one load instruction per KiB — stored where they belong with byte-aligned 16-byte stores (the first version moved
+// dwords, two loads per dword and a funnel shift to reach dword-aligned destinations: 8 load instructions per KiB).
+typedef uint32_t u32x4_fr __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_fr_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 struct WaveCopy {
-    uint32_t a[4], b[4];  // first 1 KiB of the body: 4 dwords per lane
-    uint32_t edge;        // head byte (lanes < head) or tail byte (lanes 32.. < 32 + tail)
-    uint32_t head, nw, sh;
-    bool small;
+    u32x4_fr a;   // bytes [16 lane, 16 lane + 16) of the first KiB
 };
 
 __device__ __forceinline__ void wave_copy_load(WaveCopy &c, const uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
                                                uint32_t n)
 {
-    const uint32_t tid = threadIdx.x & 63u;
-    c.head = (uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
-    c.small = n < 16u + c.head;
-    c.nw = c.small ? 0u : (n - c.head) >> 2;
-    c.sh = c.head & 3u;  // src byte offset of dst word 0 (src is aligned, head < 4)
-    c.edge = 0u;
-    if (c.small) {
-        if (tid < n) c.edge = src[tid];  // n < 19
+    const uint32_t o = (threadIdx.x & 63u) * 16u;
+    c.a = u32x4_fr{0u, 0u, 0u, 0u};
+    if (o < n) c.a = *reinterpret_cast<const u32x4_fr *>(src + o);   // (a slot is padded to 16 bytes: the last piece may read past n)
+}
+
+__device__ __forceinline__ void wave_put16(uint8_t *__restrict__ d, const u32x4_fr &v, uint32_t left)
+{
+    if (left >= 16u) {
+        *reinterpret_cast<u32x4_fr_unaligned *>(d) = v;
         return;
     }
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-    const uint32_t src_words = (n + 3u) >> 2;  // dwords of src that hold valid bytes
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t w = (uint32_t)k * 64u + tid;
-        c.a[k] = w < c.nw ? s32[w] : 0u;
-        c.b[k] = (c.sh && w < c.nw && w + 1u < src_words) ? s32[w + 1u] : 0u;
-    }
-    const uint32_t done = c.head + (c.nw << 2), tail = n - done;  // tail < 4
-    if (tid < c.head) c.edge = src[tid];
-    else if (tid >= 32u && tid - 32u < tail) c.edge = src[done + tid - 32u];
+    for (uint32_t k = 0; k < 15u; ++k)
+        if (k < left) d[k] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
 }
 
 __device__ __forceinline__ void wave_copy_store(const WaveCopy &c, uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
                                                 uint32_t n)
 {
-    const uint32_t tid = threadIdx.x & 63u;
-    if (c.small) {
-        if (tid < n) dst[tid] = (uint8_t)c.edge;
-        return;
-    }
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + c.head);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t w = (uint32_t)k * 64u + tid;
-        if (w < c.nw) d32[w] = __builtin_amdgcn_alignbyte(c.b[k], c.a[k], c.sh);
-    }
-    const uint32_t done = c.head + (c.nw << 2), tail = n - done;
-    if (tid < c.head) dst[tid] = (uint8_t)c.edge;
-    else if (tid >= 32u && tid - 32u < tail) dst[done + tid - 32u] = (uint8_t)c.edge;
-    // streams longer than 1 KiB + head: the rest, 1 KiB per pass
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-    const uint32_t src_words = (n + 3u) >> 2;
-    for (uint32_t base = 256u; base < c.nw; base += 256u) {
-        uint32_t a[4], b[4];
+    const uint32_t o = (threadIdx.x & 63u) * 16u;
+    if (o < n) wave_put16(dst + o, c.a, n - o);
+    // streams longer than 1 KiB: the rest, 4 KiB per pass with the loads in flight together
+    for (uint32_t base = 1024u; base < n; base += 4096u) {
+        u32x4_fr v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t w = base + (uint32_t)k * 64u + tid;
-            a[k] = w < c.nw ? s32[w] : 0u;
-            b[k] = (c.sh && w < c.nw && w + 1u < src_words) ? s32[w + 1u] : 0u;
+            const uint32_t q = base + (uint32_t)k * 1024u + o;
+            v[k] = u32x4_fr{0u, 0u, 0u, 0u};
+            if (q < n) v[k] = *reinterpret_cast<const u32x4_fr *>(src + q);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t w = base + (uint32_t)k * 64u + tid;
-            if (w < c.nw) d32[w] = __builtin_amdgcn_alignbyte(b[k], a[k], c.sh);
+            const uint32_t q = base + (uint32_t)k * 1024u + o;
+            if (q < n) wave_put16(dst + q, v[k], n - q);
         }
     }
 }
@@ -190,25 +172,15 @@ __device__ __forceinline__ void wg_copy(uint8_t *__restrict__ dst, const uint8_t
     wave_copy_store(c, dst, src, n);
 }
 
-__global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_t *__restrict__ scratch,
-                                                     const uint32_t *__restrict__ csize,
-                                                     const uint8_t *__restrict__ src,
-                                                     const uint32_t *__restrict__ bstart,
-                                                     const unsigned long long *__restrict__ chunk_off,
-                                                     const uint32_t *__restrict__ chunk_flags,
-                                                     uint8_t *__restrict__ dst, uint64_t dst_cap,
-                                                     uint64_t n_total_blocks, const uint8_t *__restrict__ planes, PlanesGeom pg)
+// header (block 0), bstarts entry and streams of Blosc block b of chunk `chunk`, by ONE wave.  coff / cend: where the chunk
+// starts and ends in dst; bs: the block's offset inside the chunk; gb: the block's index in the call.
+__device__ __forceinline__ void frame_block(const FrameParams &P, const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ csize,
+                                            const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t chunk, uint32_t b,
+                                            uint64_t gb, unsigned long long coff, unsigned long long cend, uint32_t memcpyed, uint32_t bs,
+                                            const uint8_t *__restrict__ planes, const PlanesGeom &pg)
 {
-    // one wave per Blosc block (blocks are a few KiB after compression: a whole workgroup per block idles)
-    const uint64_t gb = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (gb >= n_total_blocks) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t chunk = gb / P.nblocks;
-    const uint32_t b = (uint32_t)(gb - chunk * P.nblocks);
-    const unsigned long long coff = chunk_off[chunk], cend = chunk_off[chunk + 1];
-    if (cend > dst_cap) return;  // capacity error is reported by the host from chunk_off[n]
     uint8_t *cdst = dst + coff;
-    const uint32_t memcpyed = chunk_flags[chunk];
     const uint32_t cbytes = (uint32_t)(cend - coff);
     if (b == 0 && lane < P.hl) {
         // header bytes (see oracle/codec_oracle.c write_header)
@@ -254,11 +226,10 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
                     d[2u * i + h] = (uint8_t)v;
                 }
             }
-        } else if ((reinterpret_cast<uintptr_t>(s) & 3u) == 0) wg_copy(d, s, bsize);
+        } else if ((reinterpret_cast<uintptr_t>(s) & 15u) == 0 && (bsize & 15u) == 0) wg_copy(d, s, bsize);
         else for (uint32_t i = lane; i < bsize; i += 64u) d[i] = s[i];
         return;
     }
-    const uint32_t bs = bstart[chunk * P.nblocks + b];
     if (lane < 4) cdst[P.hl + 4u * b + lane] = (uint8_t)(bs >> (lane * 8));
     const bool leftover = bsize != P.blocksize;
     const uint32_t ns = (P.split && !leftover) ? P.typesize : 1u;
@@ -288,10 +259,166 @@ __global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_
     }
 }
 
+__global__ __launch_bounds__(256) void k_frame_write(FrameParams P, const uint8_t *__restrict__ scratch,
+                                                     const uint32_t *__restrict__ csize,
+                                                     const uint8_t *__restrict__ src,
+                                                     const uint32_t *__restrict__ bstart,
+                                                     const unsigned long long *__restrict__ chunk_off,
+                                                     const uint32_t *__restrict__ chunk_flags,
+                                                     uint8_t *__restrict__ dst, uint64_t dst_cap,
+                                                     uint64_t n_total_blocks, const uint8_t *__restrict__ planes, PlanesGeom pg)
+{
+    // one wave per Blosc block (blocks are a few KiB after compression: a whole workgroup per block idles).  (Round 4: a
+    // wave per PAIR of blocks, the four streams in flight together, was slower — 2.05 against 1.76 ms per 3 M x 2504 step
+    // alone, 5.5 against 2.8 ms beside the encode chain: the kernel lives on the number of waves in flight.)
+    const uint64_t gb = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (gb >= n_total_blocks) return;
+    const uint64_t chunk = gb / P.nblocks;
+    const uint32_t b = (uint32_t)(gb - chunk * P.nblocks);
+    const unsigned long long coff = chunk_off[chunk], cend = chunk_off[chunk + 1];
+    if (cend > dst_cap) return;  // capacity error is reported by the host from chunk_off[n]
+    const uint32_t memcpyed = chunk_flags[chunk];
+    frame_block(P, scratch, csize, src, dst, chunk, b, gb, coff, cend, memcpyed, memcpyed ? 0u : bstart[chunk * P.nblocks + b], planes, pg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_frame_fused (round 4): the three kernels above in ONE launch.  FR_SPLIT workgroups per chunk; each sums the sizes of
+// its chunk's blocks (bstarts: an exclusive scan over at most FR_MAXB blocks, kept in LDS), the first of them chains the
+// chunk totals into chunk offsets by a decoupled look-back over one 64-bit state word per chunk (status | launch tag |
+// value: the word carries its own data, so no fence is needed beside agent-scope atomic loads / stores), the others wait
+// for that word; then every wave copies its share of the blocks to their final place.  Chunk ids are handed out by a
+// ticket in start order, so a workgroup only ever waits for workgroups that already run.  The LZ4 kernels are complete
+// when this starts (stream order): nobody waits for data, only for the offsets of at most a few chunks in front.
+#define FR_MAXB 1024u
+#define FR_ST_AGG 1ull
+#define FR_ST_INC 2ull
+#define FR_VAL_BITS 42
+#define FR_TAG_BITS 20
+struct FrameState {
+    unsigned long long ticket;
+    unsigned long long pad_[7];
+    unsigned long long st[1];   // [n_chunks]
+};
+
+__device__ __forceinline__ unsigned long long fr_word(unsigned long long status, uint32_t tag, unsigned long long v)
+{
+    return (status << 62) | ((unsigned long long)tag << FR_VAL_BITS) | v;
+}
+
+__global__ __launch_bounds__(256) void k_frame_fused(FrameParams P, const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ csize,
+                                                     const uint8_t *__restrict__ src, FrameState *__restrict__ fs, uint32_t tag,
+                                                     uint32_t fr_split, unsigned long long *__restrict__ chunk_off, uint8_t *__restrict__ dst,
+                                                     uint64_t dst_cap, uint64_t n_chunks, const uint8_t *__restrict__ planes, PlanesGeom pg)
+{
+    __shared__ uint32_t s_bstart[FR_MAXB];
+    __shared__ uint32_t sm[8];
+    __shared__ unsigned long long s_tk, s_coff;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd(&fs->ticket, 1ull);
+        if (t + 1ull == n_chunks * fr_split) fs->ticket = 0ull;   // the last one to start: every other ticket is drawn, the next launch starts at 0
+        s_tk = t;
+    }
+    __syncthreads();
+    const uint64_t chunk = s_tk / fr_split;
+    const uint32_t q = (uint32_t)(s_tk - chunk * fr_split);
+    // ---- block sizes of the chunk -> bstarts, chunk size (every workgroup of the chunk: 256 loads)
+    uint32_t carry = P.hl + 4u * P.nblocks;
+    for (uint32_t b0 = 0; b0 < P.nblocks; b0 += 256u) {
+        const uint32_t b = b0 + threadIdx.x;
+        uint32_t sz = 0;
+        if (b < P.nblocks) {
+            const uint64_t boff = (uint64_t)b * P.blocksize;
+            const bool leftover = P.chunk_nbytes - boff < P.blocksize;
+            const uint32_t ns = (P.split && !leftover) ? P.typesize : 1u;
+            const uint32_t *cs = csize + (chunk * P.nblocks + b) * P.nwaves;
+            for (uint32_t j = 0; j < ns; ++j) sz += 4u + cs[j];
+        }
+        const uint32_t inc = frame_wave_incl_scan(sz);
+        if (lane == 63) sm[w] = inc;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = sm[i];
+            if ((uint32_t)i < w) base += x;
+            tot += x;
+        }
+        __syncthreads();
+        if (b < P.nblocks) s_bstart[b] = carry + base + inc - sz;
+        carry += tot;
+    }
+    unsigned long long cb = carry;
+    const uint32_t memcpyed = cb > P.chunk_nbytes + P.hl ? 1u : 0u;
+    if (memcpyed) cb = P.chunk_nbytes + P.hl;
+    // ---- chunk offset
+    unsigned long long *st = fs->st;
+    if (w == 0) {
+        unsigned long long coff = 0;
+        if (q == 0) {
+            if (chunk != 0) {
+                if (lane == 0) __hip_atomic_store(&st[chunk], fr_word(FR_ST_AGG, tag, cb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // look back: 64 chunks per step, the nearest inclusive word ends it
+                long long hi = (long long)chunk - 1;
+                for (;;) {
+                    const long long i = hi - (long long)lane;
+                    unsigned long long x = 0;
+                    bool ok = false;
+                    for (;;) {   // until every word down to the nearest inclusive one (or 64 of them) is of this launch
+                        x = i >= 0 ? __hip_atomic_load(&st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fr_word(FR_ST_INC, tag, 0ull);
+                        const uint32_t xt = (uint32_t)(x >> FR_VAL_BITS) & ((1u << FR_TAG_BITS) - 1u);
+                        ok = xt == tag && (x >> 62) != 0ull;
+                        const unsigned long long incm = __builtin_amdgcn_ballot_w64(ok && (x >> 62) == FR_ST_INC);
+                        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+                        // lanes in front of (= nearer than) the first inclusive one must all be there
+                        const unsigned long long need = incm ? ((incm & (0ull - incm)) << 1) - 1ull : ~0ull;
+                        if ((okm & need) == need) {
+                            const bool mine = ((need >> lane) & 1ull) != 0ull;
+                            unsigned long long v = mine ? (x & ((1ull << FR_VAL_BITS) - 1ull)) : 0ull;
+#pragma unroll
+                            for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+                            coff += (unsigned long long)__shfl(v, 0, 64);
+                            ok = incm != 0ull;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (ok) break;
+                    hi -= 64;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&st[chunk], fr_word(FR_ST_INC, tag, coff + cb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                chunk_off[chunk] = coff;
+                if (chunk + 1 == n_chunks) chunk_off[n_chunks] = coff + cb;
+            }
+        } else {
+            for (;;) {
+                const unsigned long long x = __hip_atomic_load(&st[chunk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t xt = (uint32_t)(x >> FR_VAL_BITS) & ((1u << FR_TAG_BITS) - 1u);
+                if (xt == tag && (x >> 62) == FR_ST_INC) {
+                    coff = (x & ((1ull << FR_VAL_BITS) - 1ull)) - cb;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (lane == 0) s_coff = coff;
+    }
+    __syncthreads();
+    const unsigned long long coff = s_coff, cend = coff + cb;
+    if (cend > dst_cap) return;   // capacity error is reported by the host from chunk_off[n]
+    // ---- this workgroup's share of the blocks, a wave per block
+    const uint32_t per = (P.nblocks + fr_split - 1u) / fr_split;
+    const uint32_t b_end = (q + 1u) * per < P.nblocks ? (q + 1u) * per : P.nblocks;
+    for (uint32_t b = q * per + w; b < b_end; b += 4u)
+        frame_block(P, scratch, csize, src, dst, chunk, b, chunk * P.nblocks + b, coff, cend, memcpyed, memcpyed ? 0u : s_bstart[b], planes, pg);
+}
+
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
                  PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,
                  uint32_t *d_bstart, uint64_t *d_chunk_csize, uint8_t *d_dst, uint64_t dst_cap,
-                 uint64_t *d_chunk_off, uint32_t *d_chunk_flags, hipStream_t st)
+                 uint64_t *d_chunk_off, uint32_t *d_chunk_flags, void *d_state, uint32_t tag, hipStream_t st)
 {
     if (n_chunks == 0) return HHGT_OK;
     FrameParams P;
@@ -304,6 +431,21 @@ int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_
     P.hl = format == HHGT_BLOSC2 ? 32u : 16u;
     P.chunk_nbytes = chunk_nbytes;
     P.slot_bytes = slot_bytes;
+    // HHGT_FRAME_FUSED=1: the one-launch form (k_frame_fused) — same bytes (tests/test_gpu_frame_fused.py), built and measured
+    // in round 4: framing 2.97 against 1.83 ms per 3 M x 2504 step (a ticket per workgroup on one word, a look-back chain and
+    // 8 blocks per wave against one) — so the three launches stay the default
+    static const bool fused_env = getenv("HHGT_FRAME_FUSED") && atoi(getenv("HHGT_FRAME_FUSED")) != 0;
+    if (fused_env && d_state && P.nblocks <= FR_MAXB && n_chunks < (1ull << 30) &&
+        n_chunks * (chunk_nbytes + 32) < (1ull << FR_VAL_BITS)) {
+        // workgroups per chunk: about 8 blocks per wave
+        uint32_t split = (P.nblocks + 31u) / 32u;
+        split = split < 1u ? 1u : (split > 8u ? 8u : split);
+        hipLaunchKernelGGL(k_frame_fused, dim3((uint32_t)(n_chunks * split)), dim3(256), 0, st, P, d_scratch, d_csize, d_src,
+                           static_cast<FrameState *>(d_state), tag, split, reinterpret_cast<unsigned long long *>(d_chunk_off), d_dst, dst_cap,
+                           n_chunks, d_planes, pg);
+        HIP_TRY(hipGetLastError());
+        return HHGT_OK;
+    }
     hipLaunchKernelGGL(k_frame_sizes, dim3((uint32_t)n_chunks), dim3(256), 0, st, P, d_csize, d_bstart,
                        reinterpret_cast<unsigned long long *>(d_chunk_csize), d_chunk_flags);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(256), 0, st,
@@ -316,3 +458,5 @@ int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }
+
+size_t frame_state_bytes(uint64_t n_chunks) { return sizeof(FrameState) + (size_t)n_chunks * 8u; }

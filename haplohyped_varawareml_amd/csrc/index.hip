@@ -92,22 +92,73 @@ __global__ __launch_bounds__(256) void k_index_newlines(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_index_hop<U>: the same index for text whose lines cannot be shorter than `skip` bytes — a record with S sample
+// k_index_hop<U, WALK>: the same index for text whose lines cannot be shorter than `skip` bytes — a record with S sample
 // columns has at least 2 S + 17 bytes in front of its newline, so behind every line start that many bytes need not be
-// looked at.  For the 1000G shape (lines of 4 S + 58 bytes) that is half of the text: the pass reads ~5 KB per variant
-// where k_index_newlines reads 10 KB.  A wave owns HOP_K (<= 64, the launcher's choice: 6) consecutive regions and walks
-// them line by line:
-// from `pos` it loads U KiB (16 B per lane, all loads in flight together), takes the first newline, appends it to the
-// slot list of the region it lies in (same slots / counts layout as k_index_newlines: everything downstream is
-// unchanged), looks at the first byte of the next line ('#' header lines and empty lines are short: no skip behind
-// them) and hops.  The first newline of a wave's range is found by plain scanning, so ranges need no hand-over.
-// A line that IS shorter than the bound (fewer sample columns than the header declares) is malformed either way; when
-// its newline falls into a hop it merges with the next line, and the newline is found where the merged line is read:
-// by the general encoder inside the sample columns of a KEPT record (encode.hip), by k_parse_fixed in the skipped bytes
-// of a record the filters DROP (nobody else reads those) — the same error, one record later.
-template <int U>
+// looked at.  A wave owns HOP_K (<= 64, the launcher's choice) consecutive regions and walks them line by line, appending
+// every newline to the slot list of the region it lies in (same slots / counts layout as k_index_newlines: everything
+// downstream is unchanged).  The first newline of a wave's range is found by plain scanning, so ranges need no hand-over.
+//
+// WALK = false (round 2, HHGT_INDEX_MODE=1): from `pos` the wave loads U KiB (16 B per lane, all loads in flight
+// together), takes the first newline, looks at the first byte of the next line ('#' header lines and empty lines are
+// short: no skip behind them) and hops by the bound — for the 1000G shape (lines of 4 S + 58 bytes) it reads half of
+// the text.
+//
+// WALK = true (round 4, the default): behind a newline the wave loads the HEAD of the next line — 1 KiB, 16 B per lane,
+// starting 15 bytes in front of the line so that lane 0 holds the newline itself — ranks the tabs in it (one 16-bit mask
+// per lane, a DPP prefix count, two ballots) and thereby knows where the sample columns start.  If FORMAT is exactly
+// "GT", a record of S diploid calls "a|b" has its newline at soff + 4 S - 1: the next head is loaded THERE, and when its
+// byte 15 is the newline the line has cost one load of 1 KiB instead of a search through U KiB (and nothing of the
+// sample columns was read: the index pass reads ~1.1 KB per 10 KB line).  Anything else — another FORMAT, a byte that
+// is not a newline, a '\r' in front of it, fewer than nine tabs in the head (an INFO column of more than ~900 bytes), a
+// newline inside the head, the last KiB of the text — falls back to the search, from the tighter bound soff + 2 S - 1
+// where the head gave one.  What the walk does NOT look at are sample columns, exactly like the hop: a line that is
+// shorter than its head claims is malformed either way; when its newline falls into a hop it merges with the next line,
+// and the newline is found where the merged line is read: by the encoders inside the sample columns of a KEPT record
+// (every field is matched against "a|b\t", encode.hip), by k_parse_fixed in the skipped bytes of a record the filters
+// DROP (nobody else reads those) — the same error, one record later.
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t x, uint32_t c4)
+{
+    // exact per-byte "== c" -> bit k set for byte k (c4 = the byte in all four positions)
+    const uint32_t t = x ^ c4;
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 where byte == 0
+    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+
+__device__ __forceinline__ uint32_t eq_mask16(const u32x4_t &v, uint32_t c4)
+{
+    return eq_mask4(v.x, c4) | (eq_mask4(v.y, c4) << 4) | (eq_mask4(v.z, c4) << 8) | (eq_mask4(v.w, c4) << 12);
+}
+
+// byte `off` (wave-uniform, < 1024) of a head window held 16 bytes per lane
+__device__ __forceinline__ uint32_t head_byte(const u32x4_t &v, uint32_t off)
+{
+    const uint32_t q = (off >> 2) & 3u;
+    const uint32_t d = q == 0u ? v.x : (q == 1u ? v.y : (q == 2u ? v.z : v.w));
+    return ((uint32_t)__builtin_amdgcn_readlane((int)d, (int)(off >> 4)) >> (8u * (off & 3u))) & 0xFFu;
+}
+
+// offset of the k-th (1-based) set bit of the wave's 1024-bit mask (16 bits per lane, lane order), given the exclusive
+// prefix count `cum` of the lanes' popcounts; the caller knows that there are at least k
+__device__ __forceinline__ uint32_t head_kth(uint32_t m16, uint32_t cum, uint32_t k)
+{
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(cum < k && cum + (uint32_t)__popc(m16) >= k);
+    const int l = __builtin_ctzll(b);
+    uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)m16, l);
+    const uint32_t r = k - (uint32_t)__builtin_amdgcn_readlane((int)cum, l);
+    for (uint32_t i = 1; i < r; ++i) m &= m - 1u;
+    return 16u * (uint32_t)l + (uint32_t)__builtin_ctz(m);
+}
+
+#ifndef WALK_BATCH
+#define WALK_BATCH 1   // four lines per step (below); 0: one line per step
+#endif
+#ifndef WALK_PF
+#define WALK_PF 0   // 1: two head windows in flight per wave (built and measured in round 4: index stage 2.78 against 2.40 ms — the
+                    // walk is not a latency chain at the occupancy it runs at; kept for the record)
+#endif
+template <int U, bool WALK>
 __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ slots,
-                                                   uint32_t *__restrict__ counts, uint32_t n_regions, uint32_t skip,
+                                                   uint32_t *__restrict__ counts, uint32_t n_regions, uint32_t skip, uint32_t S,
                                                    DevCounters *cnt, uint32_t HOP_K)
 {
     HHGT_WAVE_PRIO();
@@ -124,7 +175,196 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
     uint32_t cntv = 0;        // lane i: newlines found in region r_first + i
     bool overflow = false;
     uint64_t pos = beg;
-    while (pos < endw) {
+    // WALK: the position the head of the last line says its newline is at (have_cand), and where to search if it is not
+    uint64_t cand = 0, fb = 0;
+    bool have_cand = false;
+    // WALK: a line is one dependent load, so a wave is a latency chain — while the window at `cand` is on its way, the one
+    // behind the NEXT line is requested too, where that line's newline will be if the two lines are of one length (their
+    // fixed columns differ by a few bytes at most: the window starts 47 bytes in front of the guess and is taken when the
+    // newline turns out to lie in its bytes 15 .. 79).  A wrong guess costs nothing but the load.
+    uint64_t est_len = 0, pf_wb = 0;
+    bool pf_valid = false;
+    u32x4_t pf = u32x4_t{0u, 0u, 0u, 0u};
+    // appends newline q (< endw) to the slot list of its region
+    auto record = [&](uint64_t q) {
+        const uint32_t rr = (uint32_t)(q / INDEX_REGION), local = rr - r_first;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)local);
+        if (c < INDEX_CAP) {
+            if (lane == 0) slots[(size_t)rr * INDEX_CAP + c] = (uint32_t)q;
+        } else
+            overflow = true;
+        cntv += lane == local ? 1u : 0u;
+    };
+    // WALK, four lines per step (WALK_BATCH): the walk is bound by the ~300 instructions a wave issues per line, not by the
+    // latency of its one load (two windows in flight changed nothing, WALK_PF) — so the same instructions serve FOUR lines:
+    // 16 lanes x 16 bytes each look at a 256-byte window where the newline of line k + g should be if the lines are of one
+    // length (40 bytes in front of the guess), find the newline, rank the tabs behind it (row-wise DPP scan), and the lane
+    // that holds the ninth tab checks "\tGT\t" and says where the NEXT newline must be.  Then the chain is verified on the
+    // scalar side: group g's newline must sit exactly where group g - 1 said (group 0: where the candidate is).  The first
+    // link that does not hold — another width, another FORMAT, a '\r', a head of more than ~190 bytes, a '#' line — hands
+    // over to the one-line path below, which decides with its 1 KiB head or a search; two steps in a row that get nowhere
+    // switch the batches off for the rest of the wave's range.
+    bool no_batch = false, bat_off = false;
+    uint32_t bat_fail = 0;
+    // A batch reads 256 bytes of a head where the one-line path reads 1 KiB — and a record that is too short for its S
+    // samples but ends inside that KiB is recognised there (its newline is IN the head).  So a candidate that came out of
+    // a batch and turns out not to be a newline sends the wave back to the head it came from, once, with the wide window.
+    uint64_t head_p = 0;       // the (verified) newline in front of the line whose head produced `cand`
+    bool cand_batch = false;   // ... and that head was read by a batch
+    bool rehead = false;
+    while (have_cand || pos < endw) {
+        if (WALK && WALK_BATCH && have_cand && !no_batch && !bat_off && est_len != 0ull && cand >= 40ull && cand + 3ull * est_len + 216ull <= n) {
+            const uint32_t g = lane >> 4, li = lane & 15u;
+            const uint64_t L0 = est_len;   // (the windows lie where THIS length puts them; est_len moves on with the chain)
+            const uint8_t *wbase = text + (cand - 40ull);
+            const uint64_t voff = (uint64_t)g * L0 + 16ull * li;
+            const u32x4_t v = *reinterpret_cast<const u32x4_unaligned *>(wbase + voff);
+            const uint32_t nlm = eq_mask16(v, 0x0A0A0A0Au), tbm = eq_mask16(v, 0x09090909u);
+            const unsigned long long nlb = __builtin_amdgcn_ballot_w64(nlm != 0u);
+            uint32_t og[4];
+            bool vg[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t mg = (uint32_t)(nlb >> (16 * k)) & 0xFFFFu;
+                vg[k] = mg != 0u;
+                const int fl = 16 * k + __builtin_ctz(mg | 0x10000u);
+                og[k] = 16u * ((uint32_t)fl & 15u) + (uint32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)nlm, fl & 63) | 0x10000u);
+            }
+            const uint32_t o = g == 0u ? og[0] : (g == 1u ? og[1] : (g == 2u ? og[2] : og[3]));
+            const uint32_t l0 = 16u * li;
+            const uint32_t keep = l0 > o ? 0xFFFFu : (l0 + 15u <= o ? 0u : (0xFFFFu << (o - l0 + 1u)) & 0xFFFFu);
+            const unsigned long long nl2 = __builtin_amdgcn_ballot_w64((nlm & keep) != 0u);   // a second newline: the line ends inside its head
+            const uint32_t tk = tbm & keep, tc = (uint32_t)__popc(tk);
+            uint32_t incl = tc;   // inclusive count inside the row of 16 lanes
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+            const uint32_t cum = incl - tc;
+            const bool has9 = cum < 9u && incl >= 9u;
+            // in the lane of the ninth tab: its offset, "\tGT" in front of it, the next newline
+            uint32_t m9 = tk;
+            const uint32_t r1 = 8u - cum;   // lower tabs of this lane to step over (has9: 0 .. 8)
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) m9 = i < r1 ? (m9 & (m9 - 1u)) : m9;
+            const uint32_t j9 = (uint32_t)__builtin_ctz(m9 | 0x10000u) & 15u;   // byte of the lane
+            const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x111, 0xf, 0xf, false);      // previous lane's last dword
+            const uint32_t ptb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tbm, 0x111, 0xf, 0xf, false);    // ... and its tab mask
+            const uint32_t tb20 = (tbm << 4) | (ptb >> 12);           // tab bits of the 20 bytes [previous lane's last four | own 16]
+            const bool tab8 = ((tb20 >> (j9 + 1u)) & 1u) != 0u;       // byte j9 - 3 of the lane
+            const uint32_t ix = j9 + 2u, di = ix >> 2;                // bytes j9 - 2, j9 - 1 in the 20-byte array
+            const uint32_t w0 = di == 0u ? pw : (di == 1u ? v.x : (di == 2u ? v.y : (di == 3u ? v.z : v.w)));
+            const uint32_t w1 = di == 0u ? v.x : (di == 1u ? v.y : (di == 2u ? v.z : v.w));
+            const uint32_t gt2 = __builtin_amdgcn_alignbyte(w1, w0, ix & 3u) & 0xFFFFu;
+            const bool ok9 = has9 && tab8 && gt2 == 0x5447u;           // 'G' | 'T' << 8
+            const uint32_t t9 = l0 + j9;
+            const unsigned long long b9 = __builtin_amdgcn_ballot_w64(ok9);
+            // ---- the chain, on the scalar side
+            uint64_t expected = cand, fbx = fb, exp_head = head_p;
+            bool exp_batch = cand_batch;
+            bool stop = false, handed = false;
+            uint32_t advanced = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (stop || handed) continue;
+                const uint64_t nlpos = cand - 40ull + (uint64_t)k * L0 + og[k];
+                const bool cr = vg[k] && og[k] != 0u && head_byte(v, 256u * (uint32_t)k + og[k] - 1u) == '\r';
+                if (!vg[k] || nlpos != expected || cr) {   // not where it should be (or a CRLF text): the one-line path decides
+                    handed = true;
+                    continue;
+                }
+                exp_head = expected;
+                exp_batch = true;
+                if (expected >= endw) {
+                    stop = true;
+                    continue;
+                }
+                const uint32_t bits = (uint32_t)(b9 >> (16 * k)) & 0xFFFFu;
+                if (bits == 0u || ((nl2 >> (16 * k)) & 0xFFFFull) != 0ull) {
+                    // the newline is there, the head behind it is not of this shape: found again (and recorded) by the search
+                    have_cand = false;
+                    pos = expected;
+                    handed = true;
+                    expected = ~0ull;
+                    continue;
+                }
+                record(expected);
+                ++advanced;
+                const int l9 = 16 * k + __builtin_ctz(bits);
+                const uint32_t t9s = (uint32_t)__builtin_amdgcn_readlane((int)t9, l9);
+                const uint64_t soff = cand - 40ull + (uint64_t)k * L0 + t9s + 1ull;
+                const uint64_t nxt = soff + 4ull * S - 1ull;
+                est_len = nxt - expected;
+                expected = nxt;
+                fbx = soff + 2ull * S - 17ull;
+            }
+            if (stop) break;
+            if (expected != ~0ull) {   // the next candidate (unverified), for the next step or for the one-line path
+                if (expected > last_term) {   // (a line that claims to reach past the text: the search decides)
+                    have_cand = false;
+                    pos = fbx;
+                    if (pos > last_term) pos = last_term;
+                } else {
+                    cand = expected;
+                    fb = fbx > last_term ? last_term : fbx;
+                    have_cand = true;
+                }
+                head_p = exp_head;
+                cand_batch = exp_batch;
+            }
+            no_batch = handed;
+            bat_fail = advanced ? 0u : bat_fail + 1u;
+            bat_off = bat_fail >= 2u;
+            continue;
+        }
+        no_batch = false;
+        bool found = false, nb_have = false, have_head = false;
+        uint32_t nb_reg = 0, ho = 15u;   // ho: offset of the newline inside the head window
+        uint64_t p = 0;
+        u32x4_t hd = u32x4_t{0u, 0u, 0u, 0u};
+        if (WALK && have_cand) {
+            have_cand = false;
+            uint32_t c15 = 0, c14 = 0;
+            const bool use_pf = pf_valid && cand >= pf_wb + 15ull && cand <= pf_wb + 79ull;
+            pf_valid = false;
+            if (use_pf || cand + 1009ull <= n) {   // the window [cand - 15, cand + 1009) lies inside the text
+                if (use_pf) {
+                    hd = pf;
+                    ho = (uint32_t)(cand - pf_wb);
+                } else
+                    hd = *reinterpret_cast<const u32x4_unaligned *>(text + (cand - 15ull) + 16ull * lane);
+                const uint64_t pred = cand + est_len;   // the newline behind the line that starts behind `cand`
+                if (WALK_PF && est_len != 0ull && pred + 977ull <= n && cand < endw) {
+                    pf_wb = pred - 47ull;
+                    pf = *reinterpret_cast<const u32x4_unaligned *>(text + pf_wb + 16ull * lane);
+                    pf_valid = true;
+                }
+                c15 = head_byte(hd, ho);
+                c14 = head_byte(hd, ho - 1u);
+                have_head = true;
+            } else if (cand < n) {
+                c15 = text[cand];
+                c14 = text[cand - 1];
+            } else if (cand == n && virt) {
+                c15 = 0x0Au;
+                c14 = text[n - 1];
+            }
+            // ('\r' in front: bgzf_getline strips it and the sample columns are one byte shorter — not this shape)
+            if (c15 == 0x0Au && c14 != '\r') {
+                found = true;
+                p = cand;
+            } else if (cand_batch) {
+                // the head this candidate came from, once more and 1 KiB wide (no newline is recorded: head_p already is)
+                cand_batch = false;
+                rehead = true;
+                found = true;
+                have_head = false;
+                p = head_p;
+            } else {
+                pos = fb;
+                continue;
+            }
+        } else {
         const uint64_t a0 = pos & ~15ull;
         uint32_t any[U];
         u32x4_t v[U];
@@ -158,9 +398,6 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
             if (g0 + 16 <= pos) f = 0;
             any[u] = f;
         }
-        bool found = false, nb_have = false;
-        uint32_t nb_reg = 0;
-        uint64_t p = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (found) continue;
@@ -191,23 +428,74 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
             pos = a0 + (uint64_t)U * 1024u;
             continue;
         }
-        if (p >= endw) break;
-        {
-            const uint32_t rr = (uint32_t)(p / INDEX_REGION), local = rr - r_first;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)local);
-            if (c < INDEX_CAP) {
-                if (lane == 0) slots[(size_t)rr * INDEX_CAP + c] = (uint32_t)p;
-            } else
-                overflow = true;
-            cntv += lane == local ? 1u : 0u;
         }
-        uint32_t nb = 0x0Au;
-        if (nb_have) nb = nb_reg;                 // the byte behind the newline came with the same 16 bytes (15 of 16 cases)
-        else if (p + 1 < n) nb = text[p + 1];
-        pos = p + 1 + ((nb == '#' || nb == 0x0Au) ? 0u : skip);
+        if (!rehead) {
+            if (p >= endw) break;
+            record(p);
+        } else
+            no_batch = true;   // (the candidate the wide head gives is verified by the one-line path)
+        rehead = false;
+        bool hopped = false;
+        if (WALK) {
+            // the head of the line behind the newline (a search found p: one more load; the candidate's window is it already)
+            if (!have_head && p >= 15ull && p + 1009ull <= n) {
+                hd = *reinterpret_cast<const u32x4_unaligned *>(text + (p - 15ull) + 16ull * lane);
+                have_head = true;
+            }
+            if (have_head) {
+                const uint64_t wb = p - (uint64_t)ho;
+                const uint32_t nb = head_byte(hd, ho + 1u);
+                // the lane's bytes that lie behind the newline (offsets > ho): only those belong to the head
+                const uint32_t l0 = 16u * lane;
+                const uint32_t keep = l0 > ho ? 0xFFFFu : (l0 + 15u <= ho ? 0u : (0xFFFFu << (ho - l0 + 1u)) & 0xFFFFu);
+                if (nb == '#' || nb == 0x0Au) {
+                    pos = p + 1;   // header and empty lines are short: search right behind them
+                    hopped = true;
+                } else {
+                    const uint32_t nlm = eq_mask16(hd, 0x0A0A0A0Au) & keep;
+                    const unsigned long long nlb = __builtin_amdgcn_ballot_w64(nlm != 0u);
+                    if (nlb != 0ull) {
+                        // the line ends inside its head (far too short for S samples): exactly there
+                        const int l = __builtin_ctzll(nlb);
+                        pos = wb + 16ull * (uint64_t)l + (uint64_t)__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)nlm, l));
+                        hopped = true;
+                    } else {
+                        const uint32_t tbm = eq_mask16(hd, 0x09090909u) & keep;
+                        const uint32_t tc = (uint32_t)__popc(tbm);
+                        const uint32_t incl = wave_scan_sum_dpp(tc, lane);
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        if (total >= 9u) {
+                            const uint32_t t8 = head_kth(tbm, incl - tc, 8u), t9 = head_kth(tbm, incl - tc, 9u);
+                            const uint64_t soff = wb + t9 + 1ull;
+                            // S fields of at least one byte and S - 1 tabs in front of the newline (16 bytes of margin as in `skip`)
+                            const uint64_t lo = soff + 2ull * S - 17ull;
+                            const bool gt = t9 - t8 == 3u && head_byte(hd, t8 + 1u) == 'G' && head_byte(hd, t8 + 2u) == 'T';
+                            if (gt && soff + 4ull * S - 1ull <= last_term) {
+                                cand = soff + 4ull * S - 1ull;
+                                fb = lo;
+                                have_cand = true;
+                                est_len = cand - p;
+                                head_p = p;
+                                cand_batch = false;
+                            } else
+                                pos = lo;
+                            hopped = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (!hopped) {
+            uint32_t nb = 0x0Au;
+            if (nb_have) nb = nb_reg;                 // the byte behind the newline came with the same 16 bytes (15 of 16 cases)
+            else if (p + 1 < n) nb = text[p + 1];
+            // ('\r': the empty line of a CRLF text — round 3 hopped behind it and merged it with the record that follows)
+            pos = p + 1 + ((nb == '#' || nb == 0x0Au || nb == '\r') ? 0u : skip);
+        }
         // the terminator of the text's last line is always looked at: a file cut off in mid-line ends in a line shorter
         // than the bound, which has to reach the parser (and be reported), not vanish in a hop
         if (pos > last_term) pos = p + 1 > last_term ? p + 1 : last_term;
+        if (have_cand && fb > last_term) fb = p + 1 > last_term ? p + 1 : last_term;
     }
     if (overflow && lane == 0) atomicAdd(&cnt->err_density, 1ull);
     if (lane < r_cnt) counts[r_first + lane] = cntv < INDEX_CAP ? cntv : INDEX_CAP;
@@ -416,16 +704,26 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
             const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)s, l), ee = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
             const uint32_t hi = ee - ss < hop_skip ? ee : ss + hop_skip;   // (the index searched from (ss + hop_skip) & ~15 on)
             uint32_t hit = 0;
-            for (uint32_t x = ss + 16u * lane; x < hi; x += 1024u) {
-                uint32_t d[4] = {0u, 0u, 0u, 0u};
-                if ((uint64_t)x + 16ull <= n) {
-                    const u32x4_unaligned t = *reinterpret_cast<const u32x4_unaligned *>(text + x);
-                    d[0] = t.x, d[1] = t.y, d[2] = t.z, d[3] = t.w;
-                } else {
-                    for (uint32_t k = 0; k < 16u && (uint64_t)x + k < n; ++k) d[k >> 2] |= (uint32_t)text[x + k] << (8u * (k & 3u));
+            // (eight KiB per step, the loads in flight together: behind the walk a dropped record is examined from end to end,
+            // 20 KB at 5000 samples — one load per step made config 4's fixed-column stage 1.4 ms instead of 0.8)
+            for (uint32_t x0 = ss + 16u * lane; x0 < hi; x0 += 8192u) {
+                u32x4_t tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t x = x0 + 1024u * (uint32_t)u;
+                    tv[u] = u32x4_t{0u, 0u, 0u, 0u};
+                    if (x < hi && (uint64_t)x + 16ull <= n) tv[u] = *reinterpret_cast<const u32x4_unaligned *>(text + x);
                 }
-                const uint32_t m = nl_mask4(d[0]) | (nl_mask4(d[1]) << 4) | (nl_mask4(d[2]) << 8) | (nl_mask4(d[3]) << 12);
-                hit |= hi - x >= 16u ? m : (m & ((1u << (hi - x)) - 1u));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t x = x0 + 1024u * (uint32_t)u;
+                    if (x >= hi) continue;
+                    uint32_t d[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
+                    if ((uint64_t)x + 16ull > n)
+                        for (uint32_t k = 0; k < 16u && (uint64_t)x + k < n; ++k) d[k >> 2] |= (uint32_t)text[x + k] << (8u * (k & 3u));
+                    const uint32_t m = nl_mask4(d[0]) | (nl_mask4(d[1]) << 4) | (nl_mask4(d[2]) << 8) | (nl_mask4(d[3]) << 12);
+                    hit |= hi - x >= 16u ? m : (m & ((1u << (hi - x)) - 1u));
+                }
             }
             if (__ballot(hit != 0u) != 0ull && (int)lane == l) flags = (flags & LF_CHROM_NEW) | LF_RECORD | LF_MALFORMED;
         }
@@ -517,30 +815,52 @@ __global__ __launch_bounds__(256) void k_compact_kept(
 }
 
 // ---------------------------------------------------------------------------------------------
-// min_line: no line of this text can be shorter (0 = unknown).  Long lines: the hopping index reads the text behind the
-// bound only (-> the bytes it skips behind every record start; 0: the plain scan); HHGT_INDEX_HOP=0 keeps the plain scan.
-static uint32_t index_hop_skip(uint32_t min_line)
+// min_line: no line of this text can be shorter (0 = unknown).  Long lines: the hopping / walking index reads the text
+// behind the bound only (-> the bytes it skips behind every record start; 0: the plain scan).
+// mode (hhgt_set_index_mode; < 0: HHGT_INDEX_MODE, default 2): 0 the plain scan, 1 the hop by the bound, 2 the walk.
+int index_mode_default()
 {
-    static const int hop = getenv("HHGT_INDEX_HOP") ? atoi(getenv("HHGT_INDEX_HOP")) : 1;
-    return hop && min_line >= 1536u ? min_line - 16u : 0u;   // margin: the loads start at the 16-byte line in front of the target
+    static const int m = [] {
+        if (const char *e = getenv("HHGT_INDEX_MODE")) return atoi(e);
+        if (const char *e = getenv("HHGT_INDEX_HOP")) return atoi(e) ? 2 : 0;   // (round 2's switch)
+        return 2;
+    }();
+    return m < 0 ? 0 : (m > 2 ? 2 : m);
+}
+
+static uint32_t index_hop_skip(uint32_t min_line, int mode)
+{
+    if (mode < 0) mode = index_mode_default();
+    return mode && min_line >= 1536u ? min_line - 16u : 0u;   // margin: the loads start at the 16-byte line in front of the target
 }
 
 int launch_index_newlines(const uint8_t *d_text, uint64_t n, uint32_t *d_slots, uint32_t *d_counts,
-                          uint32_t n_regions, uint32_t min_line, DevCounters *d_cnt, hipStream_t st)
+                          uint32_t n_regions, uint32_t min_line, uint32_t S, int mode, DevCounters *d_cnt, hipStream_t st)
 {
-    if (const uint32_t skip = index_hop_skip(min_line)) {
-        // regions per wave.  Measured on the bench (3 M x 2504, index stage per step): 3.9 ms for 4 .. 7, 4.0-4.1 for 8, 4.3 for 12,
+    if (mode < 0) mode = index_mode_default();
+    if (const uint32_t skip = index_hop_skip(min_line, mode)) {
+        // regions per wave.  Hop, measured on the bench (3 M x 2504, index stage per step): 3.9 ms for 4 .. 7, 4.0-4.1 for 8, 4.3 for 12,
         // 4.4 for 16 and for "as many as make all waves of the launch resident at once" (11 on chr1) — longer walks per wave
         // cost more than a second, part-filled round of waves; fewer than 4 and the plain scan up to a range's first newline
         // (half a line per wave) starts to show
         static const int hop_k_env = getenv("HHGT_INDEX_HOP_K") ? atoi(getenv("HHGT_INDEX_HOP_K")) : 0;   // development
-        uint32_t K = hop_k_env > 0 ? (uint32_t)hop_k_env : 6u;
+        const bool walk = mode >= 2 && S > 0;
+        // The walk costs one dependent 1 KiB load per line, so a wave is a latency chain and every wave pays a plain scan up
+        // to the first newline of its range (half a line, in U KiB windows): as few waves as still fill the chip once —
+        // 8 workgroups of 4 waves on each of 256 CUs — at least the hop's 6 regions, at most 64 (the per-lane counters).
+        const uint32_t k_walk = (n_regions + 8191u) / 8192u;
+        uint32_t K = hop_k_env > 0 ? (uint32_t)hop_k_env : (walk ? (k_walk < 6u ? 6u : k_walk) : 6u);
         K = K > 64u ? 64u : K;
-#define HOP_LAUNCH(U)                                                                                                      \
-    hipLaunchKernelGGL((k_index_hop<U>), dim3(((n_regions + K - 1) / K + 3) / 4), dim3(256), 0, st, d_text, n, d_slots, d_counts, \
-                       n_regions, skip, d_cnt, K)
-        if (min_line >= 4096u) HOP_LAUNCH(5);
-        else HOP_LAUNCH(3);
+#define HOP_LAUNCH(U, W)                                                                                                      \
+    hipLaunchKernelGGL((k_index_hop<U, W>), dim3(((n_regions + K - 1) / K + 3) / 4), dim3(256), 0, st, d_text, n, d_slots, d_counts, \
+                       n_regions, skip, S, d_cnt, K)
+        if (min_line >= 4096u) {
+            if (walk) HOP_LAUNCH(5, true);
+            else HOP_LAUNCH(5, false);
+        } else {
+            if (walk) HOP_LAUNCH(3, true);
+            else HOP_LAUNCH(3, false);
+        }
 #undef HOP_LAUNCH
         HIP_TRY(hipGetLastError());
         return HHGT_OK;
@@ -563,11 +883,14 @@ int launch_compact_newlines(const uint32_t *d_slots, const uint32_t *d_counts, c
 int launch_parse_fixed(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl, const uint32_t *d_nlines,
                        uint32_t max_lines, const RegionFilter &region, uint32_t S, uint32_t *l_soff, uint32_t *l_lend,
                        uint32_t *l_pos, uint32_t *l_refalt, uint32_t *l_flags, uint32_t *l_keep,
-                       uint32_t *l_cnew, DevCounters *d_cnt, hipStream_t st)
+                       uint32_t *l_cnew, int mode, DevCounters *d_cnt, hipStream_t st)
 {
     if (max_lines == 0) return HHGT_OK;
-    // (the skip the hopping index used on this text, 0 for the plain scan: the same rule as launch_index_newlines)
-    const uint32_t hop_skip = index_hop_skip(S ? 2u * S + 17u : 0u);
+    if (mode < 0) mode = index_mode_default();
+    // (the skip the hopping index used on this text, 0 for the plain scan: the same rule as launch_index_newlines; the walk
+    // may have looked at nothing but the head of a record: a dropped record is examined from end to end)
+    uint32_t hop_skip = index_hop_skip(S ? 2u * S + 17u : 0u, mode);
+    if (hop_skip && mode >= 2) hop_skip = 0xFFFFFFFFu;
     hipLaunchKernelGGL(k_parse_fixed, dim3((max_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, d_nlines,
                        max_lines, region, S, l_soff, l_lend, l_pos, l_refalt, l_flags, l_keep, l_cnew, d_cnt, hop_skip);
     HIP_TRY(hipGetLastError());

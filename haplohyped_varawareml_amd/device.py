@@ -287,15 +287,25 @@ class Context:
         (include/hhgt.h hhgt_stream_create: the compress stream is restricted to 3/4 of the CUs) -> torch ExternalStream,
         destroyed with the context"""
         h = C.c_void_p()
-        check(self.lib.hhgt_stream_create(self.h, {"encode": 0, "compress": 1}[kind], C.byref(h)))
+        check(self.lib.hhgt_stream_create(self.h, {"encode": 0, "compress": 1, "frame": 2}[kind], C.byref(h)))
         self._streams = getattr(self, "_streams", [])
         self._streams.append(h)
         return torch.cuda.ExternalStream(h.value, device=self.device)
+
+    def set_frame_stream(self, stream):
+        """the framing half of every later compress call runs on `stream` (a torch stream; None: back to one stream) while the
+        caller's stream goes on with the next call's LZ4 kernels — include/hhgt.h hhgt_set_frame_stream"""
+        check(self.lib.hhgt_set_frame_stream(self.h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
 
     def set_keep_multiallelic(self, on=True):
         """NON-REFERENCE mode: multi-allelic SNP sites pass the record filter (the reference's isSNP drops them);
         genotypes carry allele indices > 1.  Off by default."""
         check(self.lib.hhgt_set_keep_multiallelic(self.h, 1 if on else 0))
+
+    def set_index_mode(self, mode):
+        """how the line index finds the newlines of long records: 2 the walk (default), 1 the hop by the bound, 0 the plain
+        scan, -1 back to the default (include/hhgt.h hhgt_set_index_mode); results are identical"""
+        check(self.lib.hhgt_set_index_mode(self.h, int(mode)))
 
     def set_clevel(self, clevel):
         """Blosc clevel analogue = candidates tried per position: 1-2: none (offset-1 runs only), 3-4: 1, 5-6: 2 (default 5,

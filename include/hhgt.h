@@ -193,6 +193,13 @@ int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
  * reference's isSNP (cpp/vcfpp.h:990-1000) drops every record with more than two alleles.  Genotypes then carry the
  * allele index as int8 (cpp/vcfpp.h:574), alt[] holds the first ALT base.  Default 0: the reference's filter. */
 int hhgt_set_keep_multiallelic(hhgt_ctx *ctx, int on);
+/* How the line index of hhgt_encode_text* finds the newlines of records of >= 760 samples (tbx_itr_next's job,
+ * cpp/vcfpp.h:1455-1484; results are identical in every mode, tests/test_gpu_index_walk.py):
+ *   2 (default) the walk: the head of each line says where its sample columns start; with FORMAT == "GT" the newline of a
+ *     record of S diploid calls is at soff + 4 S - 1, and when that byte is one the pass has read 1 KiB of the line;
+ *   1 the hop by the bound 2 S + 17 and a search behind it (round 2); 0 the plain scan of every byte; -1 back to the
+ *   default (HHGT_INDEX_MODE in the environment, else 2). */
+int hhgt_set_index_mode(hhgt_ctx *ctx, int mode);
 int hhgt_compress_chunks(hhgt_ctx *ctx, const void *d_src, uint64_t n_chunks, uint64_t chunk_nbytes,
                          int typesize, int blocksize, int format, void *d_dst, uint64_t dst_cap,
                          uint64_t *d_chunk_off, uint64_t *total_bytes, void *stream);
@@ -334,12 +341,22 @@ int hhgt_profile_read(hhgt_ctx *ctx, double *ms /*[HHGT_N_STAGES]*/, uint64_t *l
  *                         encode chain of the next block — two HBM-bound passes with latency-bound small kernels in
  *                         between — then waits for slots one workgroup at a time (k_parse_fixed: 146 us beside LZ4, 40 us
  *                         alone).  HHGT_COMPRESS_CUS=n overrides the CU count (0 = all).
+ *   HHGT_STREAM_FRAME     default priority, every CU: for hhgt_set_frame_stream
  * Destroy with hhgt_stream_destroy before hhgt_ctx_destroy.
  * ------------------------------------------------------------------------------------------- */
 #define HHGT_STREAM_ENCODE 0
 #define HHGT_STREAM_COMPRESS 1
+#define HHGT_STREAM_FRAME 2
 int hhgt_stream_create(hhgt_ctx *ctx, int kind, void **stream);
 int hhgt_stream_destroy(hhgt_ctx *ctx, void *stream);
+/* A third stream for the framing half of hhgt_compress_chunks / hhgt_compress_planes (round 4).  The LZ4 kernels of a call
+ * still run on the stream the call names; header, bstarts and the copy of the streams to their final place (k_frame_*, the
+ * filter-32001 chunk layout of vcf_to_h5.py:134-135) are queued on `stream` behind them, so that the caller's stream can
+ * go on with the LZ4 kernels of the NEXT call (the codec workspaces are double-buffered; a call waits for the framing
+ * that last read its set).  d_dst / d_chunk_off of a call are complete in `stream` order: record events THERE.  With
+ * total_bytes != NULL (the synchronous form) the call still returns with the chunks complete.  NULL: back to one stream.
+ * The stream must outlive every compress call that uses it (hhgt_stream_destroy on it resets this first). */
+int hhgt_set_frame_stream(hhgt_ctx *ctx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -54,3 +54,60 @@ def test_whole_genome_3m_x_2504(ctx):
         total_comp += total
         del text, res, dst, back
     assert total_kept == 3_000_000 and total_raw / total_comp > 3.0
+
+
+def test_whole_genome_3m_x_2504_plane_path(ctx):
+    """The path bench.py TIMES, at full size: hhgt_encode_text_planes_async (k_index_hop walk -> k_parse_fixed ->
+    k_encode_planes, device cursor, no int8 matrix) -> hhgt_pad_tail_planes_cursor -> hhgt_compress_planes (k_lz4_bitplanes
+    from planes + framing).  Per shard: the planes expand to a matrix whose sampled variants follow the generator's rule and
+    whose allele count equals the text's; every chunk decodes (GPU decoder) to the expanded planes; one chunk (a different
+    position per shard) goes through the CPU oracle's decoder."""
+    S = 2504
+    sizes = synth.shard_sizes(3_000_000)
+    rng = np.random.default_rng(33)
+    d = ctx.device
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=d)
+    total_raw = total_comp = 0
+    for ci, V in enumerate(sizes):
+        contig, seed = f"chr{ci + 1}", 1000 + ci + 1
+        tab = synth.variant_table(seed, V, S)
+        text, n = ctx.synth_fixed(contig, tab, S, seed=seed)
+        lay = dev.make_layout(S, V)
+        cap = lay.v_capacity
+        res = dev.EncodeResult(None, lay, z(cap, torch.int32), z(cap, torch.int32), z(cap, torch.uint8), z(cap, torch.uint8), 0, {}, [],
+                               torch.full((dev.planes_bytes(lay),), 0x5A, dtype=torch.uint8, device=d))   # poisoned: nothing relies on zeroed planes
+        cursor = z(1, torch.int64)
+        # (the sample padding rows 2504 .. 2559 are nobody's to write: zeroed once per buffer — bench.py allocates zeroed planes,
+        # the ingest engine does this call per input)
+        ctx.pad_tail_planes(res, cap, 0, cap // lay.vc)
+        rec = ctx.encode_text_planes_async(text, S, res, cursor, max_lines=V + 64, region=contig).wait()
+        ctx.pad_tail_planes_cursor(res, cursor)
+        assert rec.stats.n_kept == V == int(cursor.item()) and rec.stats.n_general_lines == 0 and rec.stats.n_drop_filter == 0
+        assert rec.reserved == 0
+        assert np.array_equal(res.start[:V].cpu().numpy().view(np.uint32) + 1, tab["pos"])
+        dst, off, total = ctx.compress_planes(res, fmt=dev.BLOSC2)
+        G = ctx.planes_expand(res)
+        Sc, Vc = lay.sc, lay.vc
+        n_sc, n_vc = -(-S // Sc), cap // Vc
+        Gv = G.view(torch.int8).view(n_vc, n_sc, Sc, Vc, 2)
+        pick = np.sort(rng.choice(V, 64, replace=False))
+        exp = np.concatenate([synth.genotype_bits(seed, int(v), 1, S, tab["thr"][v:v + 1]) for v in pick]).astype(np.int8)
+        pk = torch.from_numpy(pick).to(d)
+        got = Gv[pk // Vc, :, :, pk % Vc, :].reshape(len(pick), n_sc * Sc, 2)[:, :S].cpu().numpy()
+        assert np.array_equal(got, exp)
+        ones_text = int((text == ord("1")).sum().item())
+        ones_fixed = sum(str(int(p)).count("1") for p in tab["pos"]) + synth.header_text(contig, synth.sample_names(S)).count(b"1") \
+            + V * contig.count("1")
+        assert int(G.view(torch.int8).sum(dtype=torch.int64).item()) == ones_text - ones_fixed
+        chunk_nbytes = Sc * Vc * 2
+        n_chunks = G.numel() // chunk_nbytes
+        back, bad = ctx.decompress(dst, off, n_chunks, chunk_nbytes, typesize=2, blocksize=8192)
+        assert bad == 0 and torch.equal(back, G)
+        k = (ci * 37) % n_chunks
+        offs = off[k:k + 2].cpu().numpy()
+        ck = dst[int(offs[0]):int(offs[1])].cpu().numpy()
+        assert np.array_equal(oracle.blosc_decompress(ck), G[k * chunk_nbytes:(k + 1) * chunk_nbytes].cpu().numpy())
+        total_raw += G.numel()
+        total_comp += total
+        del text, res, dst, back, G
+    assert total_raw / total_comp > 6.0
