@@ -322,6 +322,9 @@ __global__ void k_encode_finish(DevCounters *cnt, uint64_t *cursor, const uint64
     if (t < HHGT_RESULT_RUNS) res->run_first[t] = t < n_runs ? run_first[t] : 0ull;
     for (uint32_t q = t; q < HHGT_RESULT_RUNS * 32u; q += blockDim.x)
         res->run_names[q >> 5][q & 31u] = (q >> 5) < n_runs ? (char)run_names[q] : 0;
+    // the counters go back to zero for the next call on this context (one memset launch less per call: counters_clean)
+    __syncthreads();
+    if (t < sizeof(DevCounters) / 8u) reinterpret_cast<unsigned long long *>(cnt)[t] = 0ull;
 }
 
 __global__ void k_set_u64(uint64_t *p, uint64_t v) { *p = v; }
@@ -515,7 +518,8 @@ static int encode_async_impl(hhgt_ctx *c, const void *d_text, uint64_t nbytes, c
     if (planes) TRY(planes_check_layout(L));
     const uint8_t *text = static_cast<const uint8_t *>(d_text);
     DevCounters *cnt = c->counters.as<DevCounters>();
-    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));
+    if (!c->counters_clean) HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));   // (the last call's epilogue did not get to zero them)
+    c->counters_clean = false;
     const uint32_t n_regions = (uint32_t)((nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION);
     if (nbytes) {
         {
@@ -527,6 +531,7 @@ static int encode_async_impl(hhgt_ctx *c, const void *d_text, uint64_t nbytes, c
                               d_alt, cnt, st));
     }
     TRY(encode_finish(c, d_cursor, L, cnt, st));
+    c->counters_clean = true;   // (calls on one context are serialised by the caller: the next one is queued behind this epilogue)
     if (h_result) {
         h_result->done = 0u;
         HIP_TRY(hipMemcpyAsync(h_result, c->result.p, sizeof(hhgt_encode_result), hipMemcpyDeviceToHost, st));
@@ -610,6 +615,7 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
     DevCounters *cnt = c->counters.as<DevCounters>();
     TRY(c->cursor.ensure(8));
     HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(DevCounters), st));
+    c->counters_clean = false;
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, c->cursor.as<uint64_t>(), v_base);
     const uint32_t n_regions = (uint32_t)((nbytes + 1 + INDEX_REGION - 1) / INDEX_REGION);
     uint32_t n_lines = 0;
@@ -637,6 +643,7 @@ extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes
     TRY(encode_stage_rest(c, text, nbytes, n_regions, n_lines, rf, L, c->cursor.as<uint64_t>(), d_G, nullptr, d_start, d_stop, d_ref,
                           d_alt, cnt, st));
     TRY(encode_finish(c, c->cursor.as<uint64_t>(), L, cnt, st));
+    c->counters_clean = true;
     hhgt_encode_result *hr = &c->h_result;
     hr->done = 0u;
     HIP_TRY(hipMemcpyAsync(c->h_result_pinned, c->result.p, sizeof(hhgt_encode_result), hipMemcpyDeviceToHost, st));

@@ -181,6 +181,7 @@ struct hhgt_ctx {
     int clevel = 5;        // Blosc clevel analogue (reference: compression_opts[4] = 5)
     int keep_multi = 0;    // hhgt_set_keep_multiallelic
     int index_mode = -1;   // hhgt_set_index_mode (< 0: HHGT_INDEX_MODE, default: the walk)
+    bool counters_clean = false;   // k_encode_finish of the last call left the DevCounters zeroed
     // profiling
     int profiling = 0;
     double stage_ms[HHGT_N_STAGES] = {0};

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
     // A batch reads 256 bytes of a head where the one-line path reads 1 KiB — and a record that is too short for its S
     // samples but ends inside that KiB is recognised there (its newline is IN the head).  So a candidate that came out of
     // a batch and turns out not to be a newline sends the wave back to the head it came from, once, with the wide window.
+    uint64_t len_other = 0, srch_soff = 0;   // bytes of the sample columns of the last record whose FORMAT was not "GT"; start of the one being searched
     uint64_t head_p = 0;       // the (verified) newline in front of the line whose head produced `cand`
     bool cand_batch = false;   // ... and that head was read by a batch
     bool rehead = false;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
                 }
                 exp_head = expected;
                 exp_batch = true;
+                srch_soff = 0ull;
                 if (expected >= endw) {
                     stop = true;
                     continue;
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
             if (c15 == 0x0Au && c14 != '\r') {
                 found = true;
                 p = cand;
+                srch_soff = 0ull;
             } else if (cand_batch) {
                 // the head this candidate came from, once more and 1 KiB wide (no newline is recorded: head_p already is)
                 cand_batch = false;
@@ -428,6 +431,10 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
             pos = a0 + (uint64_t)U * 1024u;
             continue;
         }
+        if (WALK && srch_soff != 0ull) {   // the sample columns of a record with another FORMAT: as long as the next one's, maybe
+            len_other = p - srch_soff;
+            srch_soff = 0ull;
+        }
         }
         if (!rehead) {
             if (p >= endw) break;
@@ -477,8 +484,20 @@ __global__ __launch_bounds__(256) void k_index_hop(const uint8_t *__restrict__ t
                                 est_len = cand - p;
                                 head_p = p;
                                 cand_batch = false;
-                            } else
+                            } else if (!gt && len_other != 0ull && soff + len_other <= last_term) {
+                                // another FORMAT ("GT:DP" ...): no width to compute — but such records often repeat the width
+                                // of the last one of their kind (fixed-width sub-fields): the newline is tried there, the
+                                // search from the bound stays the fallback, the encoders read every byte of a kept record
+                                cand = soff + len_other;
+                                fb = lo;
+                                have_cand = true;
+                                head_p = p;
+                                cand_batch = false;
+                                srch_soff = soff;
+                            } else {
                                 pos = lo;
+                                srch_soff = gt ? 0ull : soff;
+                            }
                             hopped = true;
                         }
                     }
@@ -739,17 +758,23 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
     } else if (i < max_lines) {
         l_keep[i] = l_cnew[i] = 0u;
     }
-    // statistics: one atomic per wave per category
+    // statistics: one atomic per WORKGROUP per category.  (One per wave was 4 k atomic adds on one address for a chr1-sized
+    // block — they retire one every ~12 ns, so the kernel took 66 us where its parse needs 20: round 4, from the kernel trace.)
+    __shared__ uint32_t s_stat[4];
     const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long b;
-    b = __ballot(flags & LF_RECORD);
-    if (lane == 0 && b) atomicAdd(&cnt->n_records, (unsigned long long)__popcll(b));
-    b = __ballot(flags & LF_DROP_REGION);
-    if (lane == 0 && b) atomicAdd(&cnt->n_drop_region, (unsigned long long)__popcll(b));
-    b = __ballot(flags & LF_DROP_FILTER);
-    if (lane == 0 && b) atomicAdd(&cnt->n_drop_filter, (unsigned long long)__popcll(b));
-    b = __ballot(flags & LF_MALFORMED);
-    if (lane == 0 && b) atomicAdd(&cnt->n_malformed, (unsigned long long)__popcll(b));
+    if (threadIdx.x < 4u) s_stat[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t kinds[4] = {LF_RECORD, LF_DROP_REGION, LF_DROP_FILTER, LF_MALFORMED};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long b = __ballot(flags & kinds[k]);
+        if (lane == 0 && b) atomicAdd(&s_stat[k], (uint32_t)__popcll(b));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4u && s_stat[threadIdx.x]) {
+        unsigned long long *dst = threadIdx.x == 0u ? &cnt->n_records : (threadIdx.x == 1u ? &cnt->n_drop_region : (threadIdx.x == 2u ? &cnt->n_drop_filter : &cnt->n_malformed));
+        atomicAdd(dst, (unsigned long long)s_stat[threadIdx.x]);
+    }
 }
 
 // one thread per line; kept lines scatter to their compacted slot
@@ -792,7 +817,20 @@ __global__ __launch_bounds__(256) void k_compact_kept(
         cnt->n_kept = (unsigned long long)l_kidx[n_lines];
         cnt->n_chrom_runs = (unsigned long long)l_crun[n_lines];
     }
-    if (!(flags & LF_KEEP)) return;
+    // kept lines that are not of the fixed-width shape go on the variable-width kernel's list: one atomic add per WAVE (config
+    // 4 has 88 k such lines per pass — one returning add each on one address was most of this kernel's time)
+    const bool keep = (flags & LF_KEEP) != 0u, slow = keep && !(flags & LF_FAST);
+    const unsigned long long sm = __ballot(slow);
+    unsigned long long slot0 = 0ull;
+    if (sm != 0ull) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __builtin_ctzll(sm);
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(&cnt->n_general, (unsigned long long)__popcll(sm));
+        base = (unsigned long long)__shfl((long long)base, leader, 64);
+        slot0 = base + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
+    }
+    if (!keep) return;
     const uint32_t k = l_kidx[i];
     uint64_t v = v_base + k;
     const uint32_t ra = l_refalt[i];
@@ -800,10 +838,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     k_lend[k] = l_lend[i];
     k_meta[k] = (flags & LF_FAST) | ((ra >> 16) << 8);  // bit2 = FAST, bits 8.. = GT key index
     redo_flag[k] = 0u;                                  // (the tile kernel's "line already queued for the general path" mark)
-    if (!(flags & LF_FAST)) {
-        unsigned long long slot = atomicAdd(&cnt->n_general, 1ull);
-        redo_list[slot] = k;
-    }
+    if (slow) redo_list[slot0] = k;
     if (ring) v %= v_capacity;   // ring of chunk columns: the tables wrap with it
     if (v < v_capacity) {
         uint32_t pos0 = l_pos[i];

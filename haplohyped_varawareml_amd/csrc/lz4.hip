@@ -798,8 +798,12 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
                            (d_planes || (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0) && slot_bytes >= 4128;
     if (bitplanes) {
         // effort: candidates tried per one along the hash chain (clevel 1-2: none, offset-1 runs only)
+        // clevel 9 — what the file-writing paths run at — also parses lazily (+ 0x100; HHGT_LZ4_LAZY=0 / 1 overrides: 1 at the
+        // default depth is the measurement of what the rule costs the bench)
         static const int depth_env = getenv("HHGT_LZ4_DEPTH") ? atoi(getenv("HHGT_LZ4_DEPTH")) : -1;
-        const int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 12);
+        static const int lazy_env = getenv("HHGT_LZ4_LAZY") ? atoi(getenv("HHGT_LZ4_LAZY")) : -1;
+        int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 12);
+        if ((lazy_env < 0 ? clevel >= 9 && depth == 12 : lazy_env != 0) && (depth == 2 || depth == 12)) depth |= 0x100;
         const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, pg, n_chunks * (chunk_nbytes / 8192), d_scratch,
                                             slot_bytes, d_csize, depth, st);
         if (rc != HHGT_OK) return rc;

@@ -38,6 +38,12 @@
 #include "common.h"
 
 #define BP_N 4096
+#ifndef BP_SELECT_SCALAR
+#define BP_SELECT_SCALAR 0   // which ones of a window the parse visits: 0 pointer doubling through LDS; 1 walked on the scalar unit
+                             // (built again in round 4, leaner than round 2's: one v_readlane + ~6 scalar instructions per coded
+                             // one, no LDS — byte-identical streams, LZ4 stage 14.0 against 12.1 ms: a taken branch and a
+                             // vector -> scalar hand-over per hop are a longer chain than twelve LDS round trips per window)
+#endif
 #ifndef BP_MAXONES
 #define BP_MAXONES 636
 #endif
@@ -56,6 +62,7 @@
 #define BP_BACK 64    // zeros in front of the one a match is pulled back over (round 2: 8)
 #define BP_STEPS 16   // exact extension of the chosen candidate
 #define BP_PICK 3     // full gaps the pick looks at (one dword of gap bytes)
+#define BP_LAZY_MIN 3 // LAZY: bytes the next one's match must reach further, on top of what giving up costs
 #ifdef BP_MARKS   // development: section markers in the ISA listing (hipcc -S -DBP_MARKS), tools/isa_sections.py counts per section
 #define BP_MARK(name) asm volatile("; ==MARK " name)
 #else
@@ -320,7 +327,7 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
 // the coding itself when every plane is marked: 6 ms for config 4's 537 k blocks); the bit map is the map of NONZERO bytes, a second map says which of them are 0xF7, every one
 // carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
 // Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
-template <int DEPTH, bool PLANES, bool EXC>
+template <int DEPTH, bool PLANES, bool EXC, bool LAZY = false>
 __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
                                                           uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize)
 {
@@ -639,6 +646,32 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
             }
         }
         BP_MARK("cand_done");
+        if (LAZY) {
+            // ---- one-step lazy rule (the file-writing paths' effort level; tools/sim/gapenc_ref.c states it): a one gives up
+            //      its match when the NEXT one lies inside that match and has a match of its own that ends further by at least
+            //      BP_LAZY_MIN + what giving up costs (the zeros this one's match was pulled back over, the zeros between this
+            //      one and the start of the next one's match).  The next one is the neighbouring lane (the window's last lane
+            //      keeps its match); in a run of lanes that all would give up, every other one does, counted from the far end.
+            const uint32_t E0 = hv ? (uint32_t)q + len : (uint32_t)(q + 1);
+            const uint32_t hvN = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(hv ? 1u : 0u), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            const uint32_t EN = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)E0, 0x130, 0xf, 0xf, false);
+            const uint32_t nbN = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nb, 0x130, 0xf, 0xf, false);
+            const int msN = (int)qn1 - 1 - (int)nbN;                      // where the next one's match starts
+            const int between = msN - (int)q1 > 0 ? msN - (int)q1 : 0;     // zeros between this one and that start
+            const bool Ln = hv & (hvN != 0u) & (lane < 63u) & (j + 1 < (int)m) & (qn1 <= E0) & ((int)EN - (int)E0 >= (int)(BP_LAZY_MIN + nb) + between);
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(Ln);
+            const unsigned long long rest = ~(lm >> lane);                 // first zero bit = end of this lane's run
+            const uint32_t tlo = (uint32_t)__builtin_ctz((uint32_t)rest | 0x80000000u), thi = (uint32_t)__builtin_ctz((uint32_t)(rest >> 32) | 0x80000000u);
+            const uint32_t t = (uint32_t)rest != 0u ? tlo : 32u + thi;     // (lm >> lane has zeros from bit 64 - lane on: the run ends inside)
+            const bool give = Ln && (t & 1u);
+            hv = hv && !give;
+            len = give ? 0u : len;
+            nb = give ? 0u : nb;
+            c1 = give ? 0u : c1;
+            a_last = give ? jj : a_last;
+            z_last = give ? 0u : z_last;
+            clamped = clamped && !give;
+        }
         const uint32_t E = hv ? (uint32_t)q + len : (uint32_t)(q + 1);   // end of what this one codes (0 for the virtual one)
         // first one at or behind E = the number of ones in front of position E.  A one that codes itself alone (E = q + 1) has
         // itself and its predecessors in front: its own P-index.  A match ends in the zeros behind the last one it covers (or
@@ -665,6 +698,20 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         if (cur < jw + 64) {   // (wave-uniform) otherwise the whole window lies inside an earlier match
             const uint32_t e0 = (uint32_t)(cur - jw);
             uint32_t jump = valid ? (nxt - (uint32_t)jw < 64u ? nxt - (uint32_t)jw : 64u) : 64u;   // nxt > j: always forward
+#if BP_SELECT_SCALAR
+            // the chain walked on the scalar side — one v_readlane and a handful of scalar instructions per coded one — instead
+            // of six rounds of flag write -> flag read -> ds_bpermute (measured slower, see BP_SELECT_SCALAR)
+            unsigned long long SEL = 0ull;
+            uint32_t c = e0, last = e0;
+            do {
+                SEL |= 1ull << c;
+                last = c;
+                c = (uint32_t)__builtin_amdgcn_readlane((int)jump, (int)c);
+            } while (c < 64u);
+            sel = __builtin_amdgcn_inverse_ballot_w64(SEL) && valid;
+            // the coded one whose successor lies outside the window hands over to the next window
+            if ((int)(jw + (int)last) < (int)m) cur = (int)__builtin_amdgcn_readlane((int)nxt, (int)last);
+#else
             const uint32_t p0 = jump;
             flag[lane] = lane == e0 ? 1u : 0u;
             flag[lane == 0u ? 64u : 69u] = 0u;
@@ -682,6 +729,7 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
             const unsigned long long ex = __builtin_amdgcn_ballot_w64(sel && p0 == 64u);
             // the coded one whose successor lies outside the window hands over to the next window
             if (ex != 0ull) cur = (int)__builtin_amdgcn_readlane((int)nxt, (int)(__ffsll((long long)ex) - 1));
+#endif
         }
         BP_MARK("sel_done");
         if (BP_SKIP >= 2) {
@@ -775,6 +823,19 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         bp_flush(S.stage, out + gop, sop, lane);
     }
     if (BP_SKIP) op = (op & 0xFFFu) + (sink & 1u);
+#ifdef BP_PROBE_HANDOFF
+    // development (round 4): the least a wave would pay to hand its stream to another workgroup INSIDE this launch (framing
+    // fused by a look-back, or "the chunk's last stream frames the chunk"): its stores drained, then one returning
+    // agent-scope atomic on a word the 256 streams of its chunk share (a spare word behind the chunk's first scratch slot).
+    // LZ4 stage with it: tools/dev/lz4_handoff.sh, DESIGN.md 3.3.
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(reinterpret_cast<uint32_t *>(scratch + (sidx & ~255ull) * slot_bytes + slot_bytes - 8u), 1u);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        op += old == 0xFFFFFFF0u ? 1u : 0u;   // (keeps the returned value alive; never true)
+    }
+#endif
     if (lane == 0) csize[sidx] = op;
     }
 bp_next:;
@@ -783,9 +844,12 @@ bp_next:;
 #undef BP_DONE
 }
 
+// depth: candidates per one; + 0x100: with the lazy rule (instantiated for 12 candidates — clevel 9 — and, for measurements, 2)
 int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
                          int depth, hipStream_t st)
 {
+    const bool lazy = (depth & 0x100) != 0;
+    depth &= 0xFF;
     if (n_blocks == 0) return HHGT_OK;
     if (n_blocks > 0x7fffffffull) {
         hhgt_set_error("lz4: too many blocks");
@@ -798,26 +862,28 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint6
     // (HHGT_LZ4_EXC=0: every marked stream goes to the byte-wise kernel, as before round 3)
     static const bool exc_env = !(getenv("HHGT_LZ4_EXC") && atoi(getenv("HHGT_LZ4_EXC")) == 0);
     const uint32_t exc_grid = (uint32_t)((n_blocks + 63) / 64 < 256u * 12u ? (n_blocks + 63) / 64 : 256u * 12u);
-#define BP_LAUNCH2(D, PL)                                                                                                   \
-    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL, false>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
+#define BP_LAUNCH2(D, PL, LZ)                                                                                               \
+    hipLaunchKernelGGL((k_lz4_bitplanes<D, PL, false, LZ>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
                        d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize)
-#define BP_LAUNCH(D)                                                                                                        \
+#define BP_LAUNCH(D, LZ)                                                                                                    \
     do {                                                                                                                    \
         if (planes) {                                                                                                       \
-            BP_LAUNCH2(D, true);                                                                                            \
+            BP_LAUNCH2(D, true, LZ);                                                                                        \
             if (exc_env)                                                                                                    \
-                hipLaunchKernelGGL((k_lz4_bitplanes<D, true, true>), dim3(exc_grid), dim3(128), 0, st, d_src, pg, (uint32_t)n_blocks, d_scratch, \
+                hipLaunchKernelGGL((k_lz4_bitplanes<D, true, true, LZ>), dim3(exc_grid), dim3(128), 0, st, d_src, pg, (uint32_t)n_blocks, d_scratch, \
                                    (uint64_t)slot_bytes, d_csize);                                                          \
         } else                                                                                                              \
-            BP_LAUNCH2(D, false);                                                                                           \
+            BP_LAUNCH2(D, false, LZ);                                                                                       \
     } while (0)
-    if (depth <= 0) BP_LAUNCH(0);
-    else if (depth == 1) BP_LAUNCH(1);
-    else if (depth == 2) BP_LAUNCH(2);
-    else if (depth <= 4) BP_LAUNCH(4);
-    else if (depth <= 8) BP_LAUNCH(8);
-    else if (depth <= 12) BP_LAUNCH(12);
-    else BP_LAUNCH(16);
+    if (lazy && depth == 2) BP_LAUNCH(2, true);
+    else if (lazy) BP_LAUNCH(12, true);
+    else if (depth <= 0) BP_LAUNCH(0, false);
+    else if (depth == 1) BP_LAUNCH(1, false);
+    else if (depth == 2) BP_LAUNCH(2, false);
+    else if (depth <= 4) BP_LAUNCH(4, false);
+    else if (depth <= 8) BP_LAUNCH(8, false);
+    else if (depth <= 12) BP_LAUNCH(12, false);
+    else BP_LAUNCH(16, false);
 #undef BP_LAUNCH
 #undef BP_LAUNCH2
     HIP_TRY(hipGetLastError());

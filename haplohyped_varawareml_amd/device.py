@@ -134,6 +134,7 @@ class Context:
         h = C.c_void_p()
         check(self.lib.hhgt_ctx_create(device, C.byref(h)))
         self.h = h
+        self.clevel = 5      # hhgt_ctx's default (the reference's compression_opts[4]); set_clevel keeps it in step
 
     def close(self):
         if getattr(self, "h", None):
@@ -309,8 +310,10 @@ class Context:
 
     def set_clevel(self, clevel):
         """Blosc clevel analogue = candidates tried per position: 1-2: none (offset-1 runs only), 3-4: 1, 5-6: 2 (default 5,
-        the reference's setting), 7: 4, 8: 8, 9: 16"""
+        the reference's setting), 7: 4, 8: 8, 9: 12 and a one-step lazy parse (what pipeline.stream_files / the converter
+        write files with)"""
         check(self.lib.hhgt_set_clevel(self.h, int(clevel)))
+        self.clevel = int(clevel)
 
     # ---- codec ---------------------------------------------------------------------------------
     def compress(self, src, chunk_nbytes, typesize=DEFAULT_TYPESIZE, blocksize=None, fmt=BLOSC2,

@@ -234,6 +234,9 @@ def _want_device_inflate(device_inflate):
     return normalize_device_inflate(device_inflate)
 
 
+FILE_CLEVEL = 9    # effort of the file-writing paths (stream_files, the converter): see stream_files
+
+
 def peek_sample_count(path, limit=64 << 20):
     """number of sample columns of a .vcf / .vcf.gz file from its #CHROM line (the first `limit` bytes of text at most), or
     0 when it cannot be told cheaply — what hhgt_ingest_opts.expect_samples wants to hear before the engine opens"""
@@ -257,7 +260,7 @@ def peek_sample_count(path, limit=64 << 20):
 
 def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=None, n_threads=0, sites_only=False,
                  fmt=dev.BLOSC2, device_inflate=None, on_header=None, on_variants=None, on_columns=None, on_end=None,
-                 files_ahead=1, expect_samples=None):
+                 files_ahead=1, expect_samples=None, clevel=None):
     """Several inputs through ONE native ingest engine (csrc/ingest.hip): the inflate of the next file overlaps the
     encode of the current one, and nothing waits on the host between blocks.
     jobs: [(path_or_host_buffer, region)]; callbacks get the job index first:
@@ -266,6 +269,27 @@ def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=No
     -> [FileStats] in job order"""
     from .ingest import Columns, Header, Ingest, InputEnd, Variants
     stats = [FileStats() for _ in jobs]
+    # effort: files are written once and read often, and this path is bound by its input (5-11 M variants/s against > 100 M
+    # for the kernels alone), so it runs at the reference's codec strength — clevel 9: twelve candidates per one and the lazy
+    # rule, 6.9x on 1000G-shaped planes where the kernel-only default (clevel 5) packs 6.4x and LZ4HC level 5, what the
+    # reference's compression_opts select (vcf_to_h5.py:135), 7.0x.  HHGT_FILE_CLEVEL / clevel= override; the context's own
+    # level is restored afterwards.
+    if clevel is None:
+        clevel = int(os.environ.get("HHGT_FILE_CLEVEL", FILE_CLEVEL))
+    prev_clevel = getattr(ctx, "clevel", 5)
+    if hasattr(ctx, "set_clevel"):
+        ctx.set_clevel(clevel)
+    try:
+        return _stream_files(ctx, jobs, stats, sc, vc, block_bytes, n_threads, sites_only, fmt, device_inflate, on_header, on_variants,
+                             on_columns, on_end, files_ahead, expect_samples)
+    finally:
+        if hasattr(ctx, "set_clevel"):
+            ctx.set_clevel(prev_clevel)
+
+
+def _stream_files(ctx, jobs, stats, sc, vc, block_bytes, n_threads, sites_only, fmt, device_inflate, on_header, on_variants, on_columns,
+                  on_end, files_ahead, expect_samples):
+    from .ingest import Columns, Header, Ingest, InputEnd, Variants
     if expect_samples is None:     # the first file's header says how wide the cohort is: the engine sizes and pins at open
         first = next((src for src, _ in jobs if isinstance(src, (str, os.PathLike))), None)
         expect_samples = peek_sample_count(first) if first is not None else 0

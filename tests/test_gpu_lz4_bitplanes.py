@@ -120,10 +120,13 @@ def test_random_planes_match_the_reference(ctx, ref, scale, seed):
         assert planes.size / total > 5.0          # the ratio the byte-wise encoder reaches on such planes is 5.12
 
 
-@pytest.mark.parametrize("clevel,depth", [(1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 12)])
+LAZY = 0x100     # gapenc_ref's depth argument: + the one-step lazy rule (what clevel 9 runs with since round 4)
+
+
+@pytest.mark.parametrize("clevel,depth", [(1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 12 | LAZY)])
 def test_effort_levels_match_the_reference(ctx, ref, clevel, depth):
-    """clevel -> candidates per one along the hash chain; every level byte-identical to the reference at that depth,
-    deeper levels no larger"""
+    """clevel -> candidates per one along the hash chain (clevel 9: twelve, and the lazy rule); every level byte-identical to
+    the reference at that depth, deeper levels no larger"""
     rng = np.random.default_rng(77)
     planes = bench_like(rng, 64)
     ctx.set_clevel(clevel)
@@ -135,7 +138,7 @@ def test_effort_levels_match_the_reference(ctx, ref, clevel, depth):
         want = ref(pl, depth)
         assert np.array_equal(got[k], want), f"clevel {clevel}: plane {k} differs from gapenc_ref(depth={depth})"
     ratio = planes.size / total
-    lo = {0: 3.1, 1: 5.6, 2: 5.9, 4: 6.1, 8: 6.2, 12: 6.25}[depth]   # (round 3's run / pull-back rules: +8 % at every depth)
+    lo = {0: 3.1, 1: 5.6, 2: 5.9, 4: 6.1, 8: 6.2, 12 | LAZY: 6.35}[depth]   # (round 3's run / pull-back rules: +8 % at every depth)
     assert ratio > lo, (clevel, ratio)
 
 
@@ -279,3 +282,49 @@ def test_missing_call_edge_planes_match_the_reference(ctx, ref):
         n_ref += 1
         assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref ({got[k].size} vs {want.size} bytes)"
     assert n_ref >= 25
+
+
+# ---- clevel 9 = twelve candidates + the one-step lazy rule: the effort level of the file-writing paths (round 4) ----------------
+@pytest.mark.parametrize("scale,frac,seed", [(1.0, 0.0, 21), (0.25, 0.0, 22), (4.0, 0.0, 23), (1.0, 0.025, 24), (2.0, 0.004, 25)])
+def test_lazy_rule_matches_the_reference(ctx, ref, scale, frac, seed):
+    """random planes (with and without missing calls) at clevel 9: every stream decodes (oracle, through the Blosc chunk) and
+    is byte-identical to gapenc_ref with the lazy rule; against twelve candidates without it the streams are smaller in sum"""
+    rng = np.random.default_rng(seed)
+    planes = bench_like(rng, 128, scale)
+    if frac:
+        planes = with_missing(rng, planes, frac)
+    ctx.set_clevel(9)
+    try:
+        got, total = (run_planes_from_bits if frac else run_planes)(ctx, planes)
+    finally:
+        ctx.set_clevel(5)
+    n_ref = lazy_bytes = plain_bytes = 0
+    for k, pl in enumerate(planes):
+        want = ref(pl, 12 | LAZY)
+        assert np.array_equal(oracle.lz4_decompress(got[k], N) if got[k].size < N else got[k], pl)
+        if want is None or want.size >= N:
+            continue
+        n_ref += 1
+        assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref with the lazy rule ({got[k].size} vs {want.size} bytes)"
+        lazy_bytes += want.size
+        plain_bytes += ref(pl, 12).size
+    assert n_ref >= (100 if scale <= 1 else 40)
+    if scale == 1.0 and not frac:
+        assert lazy_bytes < plain_bytes * 0.995
+
+
+def test_lazy_rule_edge_planes(ctx, ref):
+    planes = edge_planes()
+    if len(planes) % 2:
+        planes.append(np.zeros(N, np.uint8))
+    ctx.set_clevel(9)
+    try:
+        got, _ = run_planes(ctx, planes)
+    finally:
+        ctx.set_clevel(5)
+    for k, pl in enumerate(planes):
+        want = ref(pl, 12 | LAZY)
+        back = pl if got[k].size == N else oracle.lz4_decompress(got[k], N)
+        assert np.array_equal(back, pl), f"edge plane {k}"
+        if want is not None and want.size < N:
+            assert np.array_equal(got[k], want), f"edge plane {k}: differs from gapenc_ref with the lazy rule"
