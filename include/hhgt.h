@@ -183,10 +183,10 @@ int hhgt_pad_tail_cursor(hhgt_ctx *ctx, const hhgt_layout *lay, const uint64_t *
  * ------------------------------------------------------------------------------------------- */
 uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize);
 /* Blosc clevel analogue (the reference passes clevel 5: compression_opts[4], vcf_to_h5.py:135) = search effort, candidates
- * tried per position: 1..2: none (offset-1 runs only), 3..4: 1, 5..6: 2 (default 5), 7: 4, 8: 8, 9: 12; on 1000G-shaped
- * planes ratio 3.31 / 6.05 / 6.42 / 6.67 / 6.81 / 6.84 for 0 / 1 / 2 / 4 / 8 / 12 at about 0.45 ms more per 3 M x 2504
- * cohort and candidate (LZ4HC level 5, what the reference's setting selects: 7.01).  Every level emits the same LZ4 block
- * format. */
+ * tried per position: 1..2: none (offset-1 runs only), 3..4: 1, 5..6: 2 (default 5), 7: 4, 8: 8, 9: 12 and a one-step lazy
+ * parse; on 1000G-shaped planes ratio 3.31 / 6.05 / 6.42 / 6.67 / 6.81 / 6.92 at about 0.45 ms more per 3 M x 2504 cohort and
+ * candidate (LZ4HC level 5, what the reference's setting selects: 7.01).  Every level emits the same LZ4 block format.
+ * The file-writing paths above this header (pipeline.stream_files, the converter) run at 9: they are bound by their input. */
 int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
 /* NON-REFERENCE mode (measured separately and labelled so): with on != 0 the record filter also
  * keeps multi-allelic SNP sites — |REF| = 1 and ALT a comma-separated list of single bases from {A,C,G,T} — where the
@@ -228,7 +228,7 @@ int hhgt_decompress_chunks(hhgt_ctx *ctx, const void *d_src, const uint64_t *d_c
  * (so an encoder workgroup writes contiguous 8 KiB runs, and a compressor wave gathers the 16 pieces of its plane).
  * (ONE, EXC) = (0,0): allele 0; (1,0): allele 1; (1,1): missing, -9 (cpp/vcfpp.h:567-573); (0,1): any other value
  * (allele index >= 2, cpp/vcfpp.h:574) — its int8 byte sits at the call's ordinary position in d_G (same layout), which
- * is written there and nowhere else.  hhgt_encode_result.reserved counts those calls (saturating); d_G may be NULL where
+ * is written there and nowhere else.  hhgt_encode_result.reserved counts those calls (exactly — every record is decoded by the variable-width kernel at most once —, saturating at 2^32 - 1); d_G may be NULL where
  * the caller knows there are none (biallelic input under the reference's filter has none).
  * hhgt_planes_bytes(lay) = hhgt_layout_bytes(lay) / 4.
  *
