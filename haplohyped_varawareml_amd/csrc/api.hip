@@ -366,6 +366,14 @@ static int encode_stage_index(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes,
     return HHGT_OK;
 }
 
+// HHGT_ENC_STRIDE=0: GT:DP-style records of one column width go to the variable-width kernel like every other record that is not
+// "a|b\t" x S (round 3); default: the bit-plane tile kernel decodes them at their stride
+static bool stride_env()
+{
+    static const bool on = !(getenv("HHGT_ENC_STRIDE") && atoi(getenv("HHGT_ENC_STRIDE")) == 0);
+    return on;
+}
+
 // stages 2..: everything behind the index, sized by max_lines, counts and append position read on the device
 static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, uint32_t n_regions, uint32_t max_lines,
                              const RegionFilter &rf, const LayoutDev &L, const uint64_t *d_cursor, void *d_G, void *d_P, uint32_t *d_start, uint32_t *d_stop,
@@ -401,7 +409,7 @@ static int encode_stage_rest(hhgt_ctx *c, const uint8_t *text, uint64_t nbytes, 
                                 c->l_flags.as<uint32_t>(), c->l_kidx.as<uint32_t>(), c->l_crun.as<uint32_t>(),
                                 c->k_soff.as<uint32_t>(), c->k_lend.as<uint32_t>(), c->k_meta.as<uint32_t>(),
                                 c->redo_list.as<uint32_t>(), c->redo_flag.as<uint32_t>(), c->run_first.as<uint64_t>(), c->run_names.as<uint8_t>(),
-                                MAX_CHROM_RUNS, d_cursor, L.v_capacity, L.ring, d_start, d_stop, d_ref, d_alt, cnt, st));
+                                MAX_CHROM_RUNS, d_cursor, L.v_capacity, L.ring, d_start, d_stop, d_ref, d_alt, cnt, d_P != nullptr && stride_env(), st));
         t.stop();
     }
     if (L.S > 0) {

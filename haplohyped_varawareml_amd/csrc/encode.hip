@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256, TV == 128 ? 2 : 4) void k_encode_tiles(
 struct PlGroup {
     uint4 raw[PT_G];
     uint32_t lvalid;   // bit j: line j of the group is a kept fixed-width line (wave-uniform)
+    uint32_t lstride;  // bit j: line j is a kept record whose columns are all of one width of 5 .. 8 bytes, GT first (k_meta bits 20-23)
 };
 
 // the line table of 32 lines at once: lane j holds soff / meta of line kb + j (meta = 0 beyond the batch), so that a
@@ -289,11 +290,15 @@ __device__ __forceinline__ uint4 pl_load_line(const uint8_t *__restrict__ text, 
     return v;
 }
 
+struct __attribute__((packed)) PlU32 {
+    uint32_t v;
+};
+
 template <bool EDGE>
 __device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__restrict__ text, uint64_t n, const PlStep &stp, const int j0,
                                               uint32_t ls, uint32_t nval, uint32_t last_q)
 {
-    uint32_t lv = 0;
+    uint32_t lv = 0, lst = 0;
 #pragma unroll
     for (int j = 0; j < PT_G; ++j) {
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)stp.meta, j0 + j);
@@ -302,10 +307,12 @@ __device__ __forceinline__ void pl_load_group(PlGroup &gr, const uint8_t *__rest
         if (meta & LF_FAST) {   // (wave-uniform)
             lv |= 1u << j;
             v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
-        }
+        } else if ((meta >> 20) & 15u)
+            lst |= 1u << j;   // decoded by the second level below, at its stride
         gr.raw[j] = v;
     }
     gr.lvalid = lv;
+    gr.lstride = lst;
 }
 
 // PT_G lines -> per sample q: one[q] / exc[q], bit sh + j (haplotype 0) and bit 16 + sh + j (haplotype 1) for line j.
@@ -321,7 +328,7 @@ template <bool EDGE>
 __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, uint32_t (&one)[4], uint32_t (&exc)[4], long long kbase,
                                               const uint8_t *__restrict__ text, uint64_t n, const PlStep &stp, const int j0, uint32_t ls,
                                               uint32_t nval, uint32_t last_q, uint32_t *__restrict__ redo_list,
-                                              uint32_t *__restrict__ redo_flag, DevCounters *cnt, uint32_t lane)
+                                              uint32_t *__restrict__ redo_flag, DevCounters *cnt, uint32_t lane, uint32_t S_all)
 {
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, bad = 0;
 #pragma unroll
@@ -333,6 +340,7 @@ __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, u
         a3 |= (x.w & 0x00010001u) << (sh + j);
         bad |= ((x.x ^ PT_C) | (x.y ^ PT_C)) | ((x.z ^ PT_C) | (x.w ^ PT_C));
     }
+    bad |= gr.lstride ? 2u : 0u;   // a record decoded at its stride is the second level's (as data, not as a branch: the branch cost 86 spilled registers)
     if (__builtin_amdgcn_ballot_w64((bad & 0xFFFEFFFEu) != 0u) == 0ull) {
         one[0] |= a0, one[1] |= a1, one[2] |= a2, one[3] |= a3;
         return;
@@ -340,25 +348,71 @@ __device__ __forceinline__ void pl_pack_group(const PlGroup &gr, const int sh, u
 #pragma unroll 1
     for (int j = 0; j < PT_G; ++j) {
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)stp.meta, j0 + j);
-        if (!(meta & LF_FAST)) continue;
+        const uint32_t wd = (meta >> 20) & 15u;
+        if (!(meta & LF_FAST) && wd == 0u) continue;
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readlane((int)stp.soff, j0 + j);
-        const uint4 v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
-        const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
         uint32_t hard = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t y = xs[q] ^ PT_C;
-            const uint32_t t4 = y >> 4;
-            const uint32_t e2 = t4 & 0x00010001u;                                   // '.' in either allele
-            const uint32_t o2 = (y | t4) & 0x00010001u;                             // '1' or '.'
-            const uint32_t want = __umul24(e2, 30u) | (y & 0x00010001u & ~e2);      // what the allele bytes must then be
-            const uint32_t z = y & 0xFF00FF00u, zz = z ^ 0x00005300u;               // separator / terminator bytes
-            const uint32_t off = ((y & 0x00FF00FFu) ^ want) | (z < zz ? z : zz);
-            const uint32_t keep = off ? 0u : 0xFFFFFFFFu;
-            one[q] |= (o2 & keep) << (sh + j);
-            exc[q] |= (e2 & keep) << (sh + j);
-            hard |= off;
+        // one field "a|b\t" over the alphabet {0, 1, .} x {|, /}: bits into one[q] / exc[q], anything else -> hard
+#define PL_CLASSIFY(XQ, Q)                                                                                            \
+    do {                                                                                                               \
+        const uint32_t y = (XQ) ^ PT_C;                                                                                \
+        const uint32_t t4 = y >> 4;                                                                                    \
+        const uint32_t e2 = t4 & 0x00010001u;                              /* '.' in either allele */                  \
+        const uint32_t o2 = (y | t4) & 0x00010001u;                        /* '1' or '.' */                            \
+        const uint32_t want = __umul24(e2, 30u) | (y & 0x00010001u & ~e2); /* what the allele bytes must then be */    \
+        const uint32_t z = y & 0xFF00FF00u, zz = z ^ 0x00005300u;          /* separator / terminator bytes */          \
+        const uint32_t off = ((y & 0x00FF00FFu) ^ want) | (z < zz ? z : zz);                                           \
+        const uint32_t keep = off ? 0u : 0xFFFFFFFFu;                                                                  \
+        one[Q] |= (o2 & keep) << (sh + j);                                                                             \
+        exc[Q] |= (e2 & keep) << (sh + j);                                                                             \
+        hard |= off;                                                                                                   \
+    } while (0)
+        if (meta & LF_FAST) {   // (wave-uniform)
+            const uint4 v = pl_load_line<EDGE>(text, n, soff, ls, nval, last_q);
+            PL_CLASSIFY(v.x, 0);
+            PL_CLASSIFY(v.y, 1);
+            PL_CLASSIFY(v.z, 2);
+            PL_CLASSIFY(v.w, 3);
+        } else {
+            // a record whose columns are all `wd` (5 .. 8) bytes wide with the GT sub-field first — "a|b:dd\t": config 4's GT:DP
+            // records (round 3 sent them all to the variable-width kernel: 3.5 of config 4's 16 ms, tab ranking and one atomic
+            // per nonzero call).  Each column is checked where it stands — byte 3 is the ':' that ends the GT, no tab or
+            // newline up to the column's last byte, which is the tab (the newline for the last sample) — and classified as
+            // "a|b\t"; a column of any other shape is a field no alphabet accepts, which sends the line to the variable-width
+            // kernel like any other surprise.  One field at a time: the first level's registers stay what they were.
+            const uint32_t shb = 8u * (wd - 5u);   // where the column's last byte sits in its second dword
+            const uint8_t *lbase = text + soff;    // (wave-uniform base, 32-bit lane offsets: no 64-bit address pairs per lane)
+            const uint64_t room64 = n - (uint64_t)soff;
+            const uint32_t room = room64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room64;
+            const uint32_t lowm = shb ? (1u << shb) - 1u : 0u;
+#define PL_STRIDED(Q)                                                                                                  \
+    do {                                                                                                               \
+        uint32_t x = FILL_FIELD;                                                                                       \
+        if ((uint32_t)(Q) < nval) {                                                                                    \
+            const uint32_t vo = wd * (ls + (uint32_t)(Q));                                                             \
+            x = 0xFFFFFFFFu;                                                                                           \
+            if (vo + 8u <= room) {                                                                                     \
+                /* bytes 4 .. wd - 2 hold neither a tab nor a newline (the bytes above read 0), byte wd - 1 is the   */ \
+                /* tab (the newline behind the last sample), byte 3 the ':' that ends the GT                          */ \
+                const uint32_t d1 = reinterpret_cast<const PlU32 *>(lbase + vo + 4u)->v;                               \
+                const uint32_t low = d1 & lowm;                                                                        \
+                const uint32_t t9 = low ^ 0x09090909u, tA = low ^ 0x0A0A0A0Au;                                         \
+                uint32_t bad = (((t9 - 0x01010101u) & ~t9) | ((tA - 0x01010101u) & ~tA)) & 0x80808080u;                \
+                bad |= ((d1 >> shb) & 0xFFu) ^ (ls + (uint32_t)(Q) == S_all - 1u ? 0x0Au : 0x09u);                     \
+                const uint32_t d0 = reinterpret_cast<const PlU32 *>(lbase + vo)->v;                                    \
+                bad |= (d0 >> 24) ^ (uint32_t)':';                                                                     \
+                x = bad ? 0xFFFFFFFFu : ((d0 & 0x00FFFFFFu) | 0x09000000u);                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+        PL_CLASSIFY(x, Q);                                                                                             \
+    } while (0)
+            PL_STRIDED(0);
+            PL_STRIDED(1);
+            PL_STRIDED(2);
+            PL_STRIDED(3);
+#undef PL_STRIDED
         }
+#undef PL_CLASSIFY
         const unsigned long long bm = __builtin_amdgcn_ballot_w64(hard != 0u);
         if (bm != 0ull && lane == 0) {
             const uint32_t k = (uint32_t)(kbase + j);
@@ -408,12 +462,12 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
             pl_load_group<EDGE>(B, text, n, stp, (g + 1) * PT_G, ls, nval, last_q);
             PT_SCHED();
             pl_pack_group<EDGE>(A, (g * PT_G) & 15, o[(g * PT_G) >> 4], e[(g * PT_G) >> 4], kb + g * PT_G, text, n, stp, g * PT_G, ls, nval,
-                                last_q, redo_list, redo_flag, cnt, lane);
+                                last_q, redo_list, redo_flag, cnt, lane, S);
             PT_SCHED();
             if (g + 2 < NG) pl_load_group<EDGE>(A, text, n, stp, (g + 2) * PT_G, ls, nval, last_q);
             PT_SCHED();
             pl_pack_group<EDGE>(B, ((g + 1) * PT_G) & 15, o[((g + 1) * PT_G) >> 4], e[((g + 1) * PT_G) >> 4], kb + (g + 1) * PT_G, text, n,
-                                stp, (g + 1) * PT_G, ls, nval, last_q, redo_list, redo_flag, cnt, lane);
+                                stp, (g + 1) * PT_G, ls, nval, last_q, redo_list, redo_flag, cnt, lane, S);
             PT_SCHED();
         }
 #else
@@ -423,7 +477,7 @@ __device__ __forceinline__ void encode_planes_tile(const uint8_t *__restrict__ t
             pl_load_group<EDGE>(A, text, n, stp, g * PT_G, ls, nval, last_q);
             PT_SCHED();
             pl_pack_group<EDGE>(A, (g * PT_G) & 15, o[(g * PT_G) >> 4], e[(g * PT_G) >> 4], kb + g * PT_G, text, n, stp, g * PT_G, ls, nval,
-                                last_q, redo_list, redo_flag, cnt, lane);
+                                last_q, redo_list, redo_flag, cnt, lane, S);
             PT_SCHED();
         }
 #endif
@@ -628,7 +682,7 @@ __global__ __launch_bounds__(256) void k_encode_general(const uint8_t *__restric
     uint32_t haploid = 0, malformed = 0, n_other = 0;
     for (uint32_t idx = wave; idx < n_redo; idx += n_waves) {
         const uint32_t k = redo_list[idx];
-        const uint32_t soff = k_soff[k], lend = k_lend[k], gtidx = k_meta[k] >> 8;
+        const uint32_t soff = k_soff[k], lend = k_lend[k], gtidx = (k_meta[k] >> 8) & 0xFFFu;
         const uint64_t v = v_base + k;
         if (!lay.ring && v >= lay.v_capacity) continue;
         uint64_t vcol = v / lay.Vc;

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
     __syncthreads();
     const uint8_t *mine = reinterpret_cast<const uint8_t *>(stage[threadIdx.x]);
     auto rd = [&](uint32_t x) -> uint32_t { return (staged && x - s < 64u) ? (uint32_t)mine[x - s] : (uint32_t)text[x]; };
-    uint32_t soff = 0, pos0 = 0, refalt = 0, gtidx = 0;
+    uint32_t soff = 0, pos0 = 0, refalt = 0, gtidx = 0, stride = 0;
     if (i < n_lines) {
         if (e > s && rd(e - 1u) == '\r') --e;  // bgzf_getline strips a trailing CR
         soff = e;
@@ -665,12 +665,18 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
                                     ++k;
                                     q = q2 + 1;
                                 }
-                                if (!found) bad = true;  // vcfpp.h:550-552 "genotypes not present"
+                                if (!found || k > 0xFFFu) bad = true;  // vcfpp.h:550-552 "genotypes not present" (or 4096 keys in front of it)
                                 gtidx = k;
                                 soff = fs[9];
                                 if (!bad) {
                                     flags |= LF_KEEP;
                                     if (k == 0 && fe[8] - fs[8] == 2 && e - soff == 4u * S - 1u) flags |= LF_FAST;
+                                    else if (k == 0 && (e - soff + 1u) % S == 0u) {
+                                        // GT first and the sample columns S times some width of 5 .. 8 bytes ("a|b:dd\t"): the
+                                        // bit-plane encoder tries them at that stride (round 4; every column is checked there)
+                                        const uint32_t wd = (e - soff + 1u) / S;
+                                        if (wd >= 5u && wd <= 8u) stride = wd;
+                                    }
                                 }
                             } else {
                                 flags |= LF_KEEP;
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(256) void k_parse_fixed(const uint8_t *__restrict__
         l_soff[i] = soff;
         l_lend[i] = e;
         l_pos[i] = pos0;
-        l_refalt[i] = refalt | (gtidx << 16);
+        l_refalt[i] = refalt | ((gtidx & 0xFFFu) << 16) | (stride << 28);   // (12 bits of GT key index: a FORMAT column of 4096 keys is reported, below)
         l_flags[i] = flags;
         l_keep[i] = (flags & LF_KEEP) ? 1u : 0u;
         l_cnew[i] = (flags & LF_CHROM_NEW) ? 1u : 0u;
@@ -786,7 +792,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     uint32_t *__restrict__ k_soff, uint32_t *__restrict__ k_lend, uint32_t *__restrict__ k_meta,
     uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_flag, uint64_t *__restrict__ run_first, uint8_t *__restrict__ run_names,
     uint32_t max_runs, const uint64_t *__restrict__ d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *__restrict__ d_start,
-    uint32_t *__restrict__ d_stop, uint8_t *__restrict__ d_ref, uint8_t *__restrict__ d_alt, DevCounters *cnt)
+    uint32_t *__restrict__ d_stop, uint8_t *__restrict__ d_ref, uint8_t *__restrict__ d_alt, DevCounters *cnt, uint32_t strided)
 {
     HHGT_WAVE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -819,7 +825,10 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     }
     // kept lines that are not of the fixed-width shape go on the variable-width kernel's list: one atomic add per WAVE (config
     // 4 has 88 k such lines per pass — one returning add each on one address was most of this kernel's time)
-    const bool keep = (flags & LF_KEEP) != 0u, slow = keep && !(flags & LF_FAST);
+    // (k_meta: bit 2 FAST, bits 8-19 GT key index, bits 20-23 column stride of a GT-first record whose columns are all of one
+    // width; with `strided` — the bit-plane encoder runs — such a record is the tile kernel's, not the variable-width kernel's)
+    const bool keep = (flags & LF_KEEP) != 0u;
+    const bool slow = keep && !(flags & LF_FAST) && !(strided && (l_refalt[i < n_lines ? i : 0u] >> 28) != 0u);
     const unsigned long long sm = __ballot(slow);
     unsigned long long slot0 = 0ull;
     if (sm != 0ull) {
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(256) void k_compact_kept(
     const uint32_t ra = l_refalt[i];
     k_soff[k] = l_soff[i];
     k_lend[k] = l_lend[i];
-    k_meta[k] = (flags & LF_FAST) | ((ra >> 16) << 8);  // bit2 = FAST, bits 8.. = GT key index
+    k_meta[k] = (flags & LF_FAST) | ((ra >> 16) << 8);  // bit 2 = FAST, bits 8-19 = GT key index, bits 20-23 = column stride
     redo_flag[k] = 0u;                                  // (the tile kernel's "line already queued for the general path" mark)
     if (slow) redo_list[slot0] = k;
     if (ring) v %= v_capacity;   // ring of chunk columns: the tables wrap with it
@@ -938,12 +947,12 @@ int launch_compact_kept(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl,
                         const uint32_t *l_kidx, const uint32_t *l_crun, uint32_t *k_soff, uint32_t *k_lend,
                         uint32_t *k_meta, uint32_t *redo_list, uint32_t *redo_flag, uint64_t *run_first, uint8_t *run_names,
                         uint32_t max_runs, const uint64_t *d_cursor, uint64_t v_capacity, uint32_t ring, uint32_t *d_start,
-                        uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, hipStream_t st)
+                        uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, DevCounters *d_cnt, bool strided, hipStream_t st)
 {
     if (max_lines == 0) return HHGT_OK;
     hipLaunchKernelGGL(k_compact_kept, dim3((max_lines + 255) / 256), dim3(256), 0, st, d_text, n, d_nl, d_nlines, max_lines,
                        l_soff, l_lend, l_pos, l_refalt, l_flags, l_kidx, l_crun, k_soff, k_lend, k_meta, redo_list, redo_flag,
-                       run_first, run_names, max_runs, d_cursor, v_capacity, ring, d_start, d_stop, d_ref, d_alt, d_cnt);
+                       run_first, run_names, max_runs, d_cursor, v_capacity, ring, d_start, d_stop, d_ref, d_alt, d_cnt, strided ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return HHGT_OK;
 }

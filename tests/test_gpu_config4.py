@@ -144,7 +144,7 @@ def test_full_size_500k_x_5000_plane_path(ctx):
         del text
     ctx.pad_tail_planes_cursor(res, cursor)
     assert int(cursor.item()) == len(kept) == tot["n_kept"] and tot["n_records"] == V and tot["n_drop_filter"] == V - len(kept)
-    assert tot["n_general_lines"] == int(t["with_dp"][kept].sum()) and tot["n_haploid_padded"] == 0
+    assert tot["n_general_lines"] <= 5 and tot["n_haploid_padded"] == 0     # (the GT:DP records go through the tile kernel at their stride)
     assert np.array_equal(res.start[:len(kept)].cpu().numpy().view(np.uint32) + 1, t["pos"][kept])
     dst, off, total = ctx.compress_planes(res, fmt=dev.BLOSC2)
     G = ctx.planes_expand(res)

@@ -95,7 +95,9 @@ def test_mixed_c4_planes_vs_oracle(ctx):
     res, nk, recs = _encode_planes(ctx, host, S, lay, "chr4", 3, with_g=False, max_lines=lambda t_: t_.numel() // 16 + 8)
     assert nk == o["n_kept"] and sum(r.stats.n_drop_filter for r in recs) == o["stats"]["n_drop_filter"]
     assert all(r.reserved == 0 for r in recs)                 # under the reference's filter: 0, 1 and missing only
-    assert sum(r.stats.n_general_lines for r in recs) == int(t["with_dp"][np.nonzero(t["kept"])[0]].sum())
+    # (round 4: the GT:DP records of this text have columns of one width — "a|b:dd" — and are decoded by the tile kernel at that
+    # stride; the variable-width kernel only sees a record whose last columns sit within 8 bytes of the end of a text block)
+    assert sum(r.stats.n_general_lines for r in recs) <= 3 < int(t["with_dp"][np.nonzero(t["kept"])[0]].sum())
     back = ctx.planes_expand(res)
     G = _dense_from_bytes(back, lay, nk)
     assert (o["G"] == -9).any()
@@ -296,3 +298,59 @@ def test_bad_layout_is_refused(ctx):
     res = dev.EncodeResult(None, lay, None, None, None, None, 0, {}, [], torch.zeros(4096, dtype=torch.uint8, device=ctx.device))
     with pytest.raises(dev.HhgtError):
         ctx.encode_text_planes_async(to_dev(b"#x\n"), 10, res, torch.zeros(1, dtype=torch.int64, device=ctx.device))
+
+
+@pytest.mark.parametrize("S", [5, 257, 700])
+def test_columns_of_one_width_go_through_the_tile_kernel(ctx, S):
+    """Round 4: a kept record whose FORMAT starts with GT and whose sample columns are all of one width of 5 .. 8 bytes ("a|b:dd",
+    config 4's GT:DP records) is decoded by k_encode_planes at that stride — every column checked where it stands — instead of
+    by the variable-width kernel.  Widths 5 .. 9, missing and unphased calls, and the records that only LOOK regular (the total
+    length fits, two columns trade a byte; a tab inside a sub-field's place; a third allele; CRLF): all equal to the oracle, and
+    only the irregular ones reach the variable-width kernel."""
+    rng = np.random.default_rng(S)
+    hdr = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + b"\t".join(b"s%d" % i for i in range(S)) + b"\n"
+    gts = [b"0|0", b"0|1", b"1|0", b"1|1", b"./.", b".|1", b"0/1", b"0|."]
+    lines, irregular = [], 0
+    for v in range(400):
+        kind = v % 10
+        g = [gts[i] for i in rng.integers(0, len(gts), S)]
+        fmt = b"GT:DP"
+        if kind == 0:
+            cols = [x + b":%d" % rng.integers(0, 10) for x in g]                     # width 6
+        elif kind in (1, 2, 3):
+            cols = [x + b":%02d" % rng.integers(10, 100) for x in g]                  # width 7 (config 4's shape)
+        elif kind == 4:
+            cols = [x + b":%03d" % rng.integers(100, 1000) for x in g]                # width 8
+        elif kind == 5:
+            cols = [x + b":" for x in g]                                              # width 5: an empty second sub-field
+        elif kind == 6:
+            fmt = b"GT:GQ:DP"
+            cols = [x + b":9:%02d" % rng.integers(10, 100) for x in g]                # width 9: not this path
+            irregular += 1
+        elif kind == 7 and S >= 2:
+            cols = [x + b":%02d" % rng.integers(10, 100) for x in g]                  # the length fits, two columns trade a byte
+            i, k = sorted(rng.choice(S, 2, replace=False))
+            cols[i] = g[i] + b":100"
+            cols[k] = g[k] + b":7"
+            irregular += 1
+        elif kind == 8:
+            cols = [x + b":%02d" % rng.integers(10, 100) for x in g]
+            cols[int(rng.integers(0, S))] = b"2|1:33"                                  # a third allele: same width, not this alphabet
+            irregular += 1
+        else:
+            cols = [x + b":%02d" % rng.integers(10, 100) for x in g]
+            cols[int(rng.integers(0, S))] = b"10|1:" if S > 1 else cols[0]            # a two-digit allele in a column of the same width
+            irregular += S > 1
+        lines.append(b"chr3\t%d\t.\tA\tC\t.\tPASS\t.\t" % (100 + 7 * v) + fmt + b"\t" + b"\t".join(cols))
+    for text in (hdr + b"\n".join(lines) + b"\n", hdr + b"\r\n".join(lines[:40]) + b"\r\n"):
+        crlf = b"\r\n" in text[len(hdr):]
+        o = oracle.vcf_encode(text, S, region="chr3")
+        lay = dev.make_layout(S, -(-o["n_kept"] // 4096) * 4096, sc=64, vc=4096)
+        res, nk, recs = _encode_planes(ctx, text, S, lay, "chr3", 3, max_lines=lambda t_: t_.numel() // 16 + 8)
+        assert nk == o["n_kept"] == (40 if crlf else 400)
+        G = _dense_from_bytes(ctx.planes_expand(res), lay, nk)
+        assert np.array_equal(G, o["G"])
+        n_gen = sum(r.stats.n_general_lines for r in recs)
+        if not crlf:
+            assert irregular <= n_gen <= irregular + 6, (n_gen, irregular)   # (+ a record whose last columns sit at the end of a text block)
+        assert sum(r.stats.n_haploid_padded for r in recs) == o["stats"]["n_haploid_padded"]
