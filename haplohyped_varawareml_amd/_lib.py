@@ -101,6 +101,7 @@ def load():
     L.hhgt_encode_chrom_runs.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(C.c_uint32)]
     L.hhgt_pad_tail.argtypes = [vp, C.POINTER(Layout), u64, u64, u64, vp, vp]
     L.hhgt_set_clevel.argtypes = [vp, i32]
+    L.hhgt_reserve.argtypes = [vp, u64, C.c_uint32, u64, u64, i32, i32]
     L.hhgt_set_keep_multiallelic.argtypes = [vp, i32]
     L.hhgt_set_index_mode.argtypes = [vp, i32]
     L.hhgt_stream_create.argtypes = [vp, i32, C.POINTER(vp)]

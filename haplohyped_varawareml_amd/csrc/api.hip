@@ -603,10 +603,37 @@ extern "C" int hhgt_planes_expand(hhgt_ctx *c, const hhgt_layout *lay, const voi
                                 static_cast<uint8_t *>(d_out), reinterpret_cast<hipStream_t>(stream));
 }
 
+static int encode_text_once(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region, const hhgt_layout *lay, uint64_t v_base,
+                            void *d_G, uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_stats *stats,
+                            void *stream);
+
+// The synchronous form decodes whatever the plain scan decodes: when the call comes back MALFORMED and the line index of long
+// records skipped bytes (hop / walk, S >= 760), the reason may be a newline in the part it did not look at — a record shorter
+// than its S samples that is valid VCF all the same (rows of empty columns; one haploid call + one two-digit allele in front of
+// an empty line: DESIGN.md 4).  Then the call runs once more with every byte scanned (mode 0) and THAT outcome stands: an
+// error only where the scan errs too.  Costs nothing unless the first pass fails.  (The asynchronous form reports the first
+// pass's error — its callers have queued more work behind it.)
 extern "C" int hhgt_encode_text(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region,
                                 const hhgt_layout *lay, uint64_t v_base, void *d_G, uint32_t *d_start,
                                 uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_stats *stats,
                                 void *stream)
+{
+    int rc = encode_text_once(c, d_text, nbytes, region, lay, v_base, d_G, d_start, d_stop, d_ref, d_alt, stats, stream);
+    if (rc == HHGT_ERR_MALFORMED && c && lay && lay->n_samples >= 760) {
+        const int mode = c->index_mode < 0 ? index_mode_default() : c->index_mode;
+        if (mode > 0) {
+            const int saved = c->index_mode;
+            c->index_mode = 0;
+            rc = encode_text_once(c, d_text, nbytes, region, lay, v_base, d_G, d_start, d_stop, d_ref, d_alt, stats, stream);
+            c->index_mode = saved;
+        }
+    }
+    return rc;
+}
+
+static int encode_text_once(hhgt_ctx *c, const void *d_text, uint64_t nbytes, const char *region, const hhgt_layout *lay, uint64_t v_base,
+                            void *d_G, uint32_t *d_start, uint32_t *d_stop, uint8_t *d_ref, uint8_t *d_alt, hhgt_encode_stats *stats,
+                            void *stream)
 {
     if (!c) return HHGT_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -866,6 +893,53 @@ extern "C" int hhgt_compress_planes(hhgt_ctx *c, const hhgt_layout *lay, const v
     const uint8_t *g = d_G ? static_cast<const uint8_t *>(d_G) + (uint64_t)col0 * col_bytes : nullptr;
     return compress_impl(c, g, d_P, pg, (uint64_t)n_cols * L.n_sc, chunk_nbytes, 2, 8192, format, d_dst, dst_cap, d_chunk_off, total_bytes,
                          stream);
+}
+
+// Workspaces of the context made ahead of time for calls of a known size (they otherwise grow inside the first calls: hipMalloc
+// of hundreds of MB each, in the middle of a pipeline's first pass).  text_bytes / max_lines: the largest encode call to come;
+// n_chunks x chunk_nbytes (typesize, blocksize): the largest compress call.  Either half may be 0.
+extern "C" int hhgt_reserve(hhgt_ctx *c, uint64_t text_bytes, uint32_t max_lines, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+                            int blocksize)
+{
+    if (!c) return HHGT_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (text_bytes) {
+        const uint32_t n_regions = (uint32_t)((text_bytes + 1 + INDEX_REGION - 1) / INDEX_REGION);
+        TRY(c->slots.ensure((size_t)n_regions * INDEX_CAP * 4));
+        TRY(c->counts.ensure((size_t)n_regions * 4));
+        TRY(c->prefix.ensure(((size_t)n_regions + 1) * 4));
+        const size_t st_el = scan_tmp_elems(n_regions) > scan_tmp_elems(max_lines) ? scan_tmp_elems(n_regions) : scan_tmp_elems(max_lines);
+        TRY(c->scan_tmp.ensure(2 * st_el * 4));
+        const size_t nl4 = ((size_t)max_lines + 1) * 4;
+        TRY(c->nl.ensure(nl4));
+        DevBuf *per_line[] = {&c->l_soff, &c->l_lend, &c->l_pos, &c->l_refalt, &c->l_flags, &c->l_keep, &c->l_kidx, &c->l_cnew, &c->l_crun,
+                              &c->k_soff, &c->k_lend, &c->k_meta, &c->redo_list, &c->redo_flag};
+        for (DevBuf *b : per_line) TRY(b->ensure(nl4));
+        TRY(c->run_first.ensure(MAX_CHROM_RUNS * 8));
+        TRY(c->run_names.ensure(MAX_CHROM_RUNS * 32));
+        TRY(c->result.ensure(sizeof(hhgt_encode_result)));
+    }
+    if (n_chunks) {
+        TRY(check_codec_args(chunk_nbytes, typesize, blocksize, HHGT_BLOSC2));
+        blocksize = effective_blocksize(chunk_nbytes, typesize, blocksize);
+        uint32_t nblocks, nwaves;
+        size_t slot;
+        codec_geometry(chunk_nbytes, typesize, blocksize, &nblocks, &nwaves, &slot);
+        const uint64_t n_streams = n_chunks * nblocks * nwaves;
+        hhgt_ctx::CodecWs &w = c->cw[0];
+        TRY(w.lz_scratch.ensure((size_t)n_streams * slot));
+        TRY(w.lz_csize.ensure((size_t)n_streams * 4));
+        TRY(w.fr_bsize.ensure((size_t)n_chunks * nblocks * 4));
+        TRY(w.fr_csize.ensure(((size_t)n_chunks + 1) * 8));
+        TRY(w.fr_flags.ensure((size_t)n_chunks * 4));
+        const size_t cap0 = w.fr_state.cap;
+        TRY(w.fr_state.ensure(frame_state_bytes(n_chunks)));
+        if (w.fr_state.cap != cap0) {
+            HIP_TRY(hipMemset(w.fr_state.p, 0, w.fr_state.cap));
+            w.fr_tag = 0;
+        }
+    }
+    return HHGT_OK;
 }
 
 extern "C" int hhgt_set_clevel(hhgt_ctx *c, int clevel)

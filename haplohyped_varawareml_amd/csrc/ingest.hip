@@ -1003,6 +1003,7 @@ bool queue_columns(hhgt_ingest *g, Input *in, uint64_t c0, uint64_t c1)
         b.n_chunks = n * X->n_sc;
         b.raw_bytes = n * X->col_bytes;
         if (!g->free_dst.pop(b.dst_slot) || !get_event(g, &b.ev)) return false;
+        trace("drv:dst_slot", (long long)n);
         DstSlot &d = g->dst[(size_t)b.dst_slot];
         const int bs = g->o.blocksize;
         if (X->planes)
@@ -1011,8 +1012,10 @@ bool queue_columns(hhgt_ingest *g, Input *in, uint64_t c0, uint64_t c1)
         else
             G_TRY(hhgt_compress_chunks(g->ctx, X->G.as<uint8_t>() + slot * X->col_bytes, b.n_chunks, X->chunk_nbytes, g->o.typesize, bs,
                                        g->o.format, d.d.p, d.d.cap, d.off.as<uint64_t>(), nullptr, g->s_main));
+        trace("drv:compress_queued", (long long)b.n_chunks);
         G_HIP(hipMemcpyAsync(d.h_off.p, d.off.p, (size_t)((b.n_chunks + 1) * 8), hipMemcpyDeviceToHost, g->s_main));
         G_HIP(hipEventRecord(b.ev, g->s_main));
+        trace("drv:off_copy_queued");
         g->q_ship.push(b);
         c0 += n;
     }
@@ -1097,6 +1100,7 @@ bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
         v.first_variant = a;
         v.n_variants = b - a;
         if (!g->free_var.pop(v.var_slot) || !get_event(g, &v.ev)) return false;
+        trace("drv:var_slot");
         VarSlot &vs = g->var[(size_t)v.var_slot];
         const uint64_t cap = X->lay.v_capacity;
         if (!ring_d2h(g, vs.start.p, X->t_start.p, a, b, cap, 4) || !ring_d2h(g, vs.ref.p, X->t_ref.p, a, b, cap, 1) ||
@@ -1371,12 +1375,62 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
         const uint64_t S = g->o.sites_only ? 0ull : (uint64_t)g->o.expect_samples;
         bool ok = size_input_state(g, &g->ist[0], S, (uint64_t)g->o.expect_samples, bb + 256, true) &&
                   size_input_state(g, &g->ist[1], S, (uint64_t)g->o.expect_samples, bb + 256, true);
+        if (ok) {   // the context's own workspaces for a block / a batch of that size
+            const hhgt_ingest::InState &X0 = g->ist[0];
+            const uint64_t W = X0.kept_per_block / (uint64_t)g->o.vc + 2;
+            ok = hhgt_reserve(g->ctx, bb + 256, (uint32_t)X0.kept_per_block, (W + 2) * X0.n_sc, X0.chunk_nbytes, g->o.typesize,
+                              g->o.blocksize) == HHGT_OK;
+        }
         if (ok && dev) {
             const uint64_t want = (uint64_t)((double)bb_dev / 24.0 * 1.15) + (256u << 10);
             const size_t tab_room = (size_t)(want / 26 + 2) * 28 + 64;
             for (auto &sg : g->stg) ok = ok && sg.h.ensure((size_t)want + 64 + tab_room) == HHGT_OK;
         }
         if (ok && g->o.device_inflate != 1) hhgt_reader_prewarm(bb_host, 6 * ((g->o.files_ahead > 0 ? g->o.files_ahead : 1) + 1));
+        if (ok && S > 0) {
+            // one chunk column through the compressor on the engine's stream: the first launch of a kernel that spills
+            // (k_lz4_blocks) makes the runtime allocate the queue's scratch arena — 28 ms inside the first batch of the first
+            // input otherwise (HHGT_INGEST_DEBUG: "harvest work" 28.1 ms against 0.3)
+            hhgt_ingest::InState &X0 = g->ist[0];
+            DstSlot &d0 = g->dst[0];
+            if (X0.planes) {
+                ok = hipMemsetAsync(X0.P.p, 0, (size_t)hhgt_planes_bytes(&X0.lay), g->s_main) == hipSuccess &&
+                     hhgt_compress_planes(g->ctx, &X0.lay, X0.P.p, X0.G.p, 0u, 1u, g->o.format, d0.d.p, d0.d.cap, d0.off.as<uint64_t>(), nullptr,
+                                          g->s_main) == HHGT_OK;
+            } else {
+                ok = hipMemsetAsync(X0.G.p, 0, (size_t)X0.col_bytes, g->s_main) == hipSuccess &&
+                     hhgt_compress_chunks(g->ctx, X0.G.p, X0.n_sc, X0.chunk_nbytes, g->o.typesize, g->o.blocksize, g->o.format, d0.d.p, d0.d.cap,
+                                          d0.off.as<uint64_t>(), nullptr, g->s_main) == HHGT_OK;
+            }
+            ok = ok && hipStreamSynchronize(g->s_main) == hipSuccess;
+        }
+        if (ok) {
+            // ... and one small copy each way on every stream the engine copies on (the first copy of a direction on a stream
+            // sets the runtime's copy path up: milliseconds, once)
+            hhgt_ingest::InState &X0 = g->ist[0];
+            DstSlot &d0 = g->dst[0];
+            uint8_t *h8 = d0.h_off.p;   // pinned, >= 16 bytes
+            for (hipStream_t st : {g->s_main, g->s_copy, g->s_inf, g->s_out}) {
+                ok = ok && hipMemcpyAsync(X0.cursor.p, h8, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+                     hipMemcpyAsync(h8 + 8, X0.cursor.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipMemsetAsync(X0.cursor.p, 0, 8, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            }
+            // ... and every pinned buffer the device will copy into is copied into once, in full (HHGT_INGEST_DEBUG=2 showed the
+            // first device -> host copy into each fresh pinned slot taking 7-10 ms where later ones take microseconds)
+            if (S > 0) {
+                for (auto &v : g->var) {
+                    const size_t n4 = v.start.cap < X0.t_start.cap ? v.start.cap : X0.t_start.cap, n1 = v.ref.cap < X0.t_ref.cap ? v.ref.cap : X0.t_ref.cap;
+                    ok = ok && hipMemcpyAsync(v.start.p, X0.t_start.p, n4, hipMemcpyDeviceToHost, g->s_main) == hipSuccess &&
+                         hipMemcpyAsync(v.ref.p, X0.t_ref.p, n1, hipMemcpyDeviceToHost, g->s_main) == hipSuccess &&
+                         hipMemcpyAsync(v.alt.p, X0.t_alt.p, n1, hipMemcpyDeviceToHost, g->s_main) == hipSuccess;
+                }
+                for (auto &d : g->dst)
+                    ok = ok && hipMemcpyAsync(d.h_off.p, d.off.p, d.h_off.cap < d.off.cap ? d.h_off.cap : d.off.cap, hipMemcpyDeviceToHost, g->s_main) == hipSuccess;
+                for (auto &o : g->out)
+                    ok = ok && hipMemcpyAsync(o.h.p, d0.d.p, o.h.cap < d0.d.cap ? o.h.cap : d0.d.cap, hipMemcpyDeviceToHost, g->s_out) == hipSuccess;
+                ok = ok && hipStreamSynchronize(g->s_main) == hipSuccess && hipStreamSynchronize(g->s_out) == hipSuccess;
+            }
+        }
         if (!ok) {
             hhgt_ingest_close(g);
             return HHGT_ERR_HIP;

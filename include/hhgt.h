@@ -106,6 +106,9 @@ typedef struct {
  *   stats         : host struct, filled on return.
  * Synchronises `stream` before returning (counts are read back).  On HHGT_ERR_MALFORMED the
  * outputs are undefined (the reference raises RuntimeError / asserts).
+ * Records of >= 760 samples: the line index does not look at every byte (hhgt_set_index_mode); a pass that comes back
+ * MALFORMED is run once more with every byte scanned before this call reports anything, so the outcome is the plain
+ * scan's (round 4; the asynchronous forms below make one pass and report it).
  */
 int hhgt_encode_text(hhgt_ctx *ctx, const void *d_text, uint64_t nbytes, const char *region,
                      const hhgt_layout *lay, uint64_t v_base, void *d_G, uint32_t *d_start,
@@ -188,6 +191,11 @@ uint64_t hhgt_compress_bound(uint64_t n_chunks, uint64_t chunk_nbytes, int types
  * candidate (LZ4HC level 5, what the reference's setting selects: 7.01).  Every level emits the same LZ4 block format.
  * The file-writing paths above this header (pipeline.stream_files, the converter) run at 9: they are bound by their input. */
 int hhgt_set_clevel(hhgt_ctx *ctx, int clevel);
+/* Makes the context's workspaces for the largest encode call (text_bytes, max_lines) and the largest compress call (n_chunks
+ * chunks of chunk_nbytes, typesize, blocksize) to come, instead of letting them grow inside the first calls (round 4: what
+ * hhgt_ingest_open does when its caller names the sample count).  Either half may be 0.  No counterpart in the reference. */
+int hhgt_reserve(hhgt_ctx *ctx, uint64_t text_bytes, uint32_t max_lines, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
+                 int blocksize);
 /* NON-REFERENCE mode (measured separately and labelled so): with on != 0 the record filter also
  * keeps multi-allelic SNP sites — |REF| = 1 and ALT a comma-separated list of single bases from {A,C,G,T} — where the
  * reference's isSNP (cpp/vcfpp.h:990-1000) drops every record with more than two alleles.  Genotypes then carry the

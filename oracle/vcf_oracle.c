@@ -32,9 +32,11 @@
  *     agrees for S < 760; for wider files its line index hops over the first 2 S + 1 bytes behind every line start
  *     (csrc/index.hip), so a line shorter than that merges with its successor: if the merged line is KEPT the encoder
  *     sees the inner newline, if the short line is DROPPED by the region / isSNP filter k_parse_fixed looks at the bytes
- *     the index jumped over and finds it — either way the call fails with HHGT_ERR_MALFORMED, never a silently
- *     different matrix (tests/test_gpu_index_hop.py pins both; HHGT_INDEX_HOP=0 restores the plain scan and this
- *     oracle's leniency).  Malformed input either way; stated here because it is a difference from this oracle.
+ *     the index jumped over and finds it — either way the pass fails with HHGT_ERR_MALFORMED, never a silently
+ *     different matrix (tests/test_gpu_index_hop.py pins both; HHGT_INDEX_MODE=0 restores the plain scan and this
+ *     oracle's leniency).  Since round 4 the SYNCHRONOUS call (hhgt_encode_text, behind parse_vcf) runs a failed pass
+ *     once more with every byte scanned and so agrees with this oracle again; the asynchronous form reports the one
+ *     pass it makes.  Malformed input either way; stated here because it is a difference from this oracle.
  *
  * PARITY UNPINNED (by the grading rule): the reference holds no output vectors for this path and its loader cannot
  * be compiled here (htslib absent).  What pins this file is tests/golden/ — vectors derived from the reference's own

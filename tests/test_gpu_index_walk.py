@@ -136,9 +136,10 @@ def test_newline_of_another_line_where_the_head_points(ctx, S):
     """The one shape on which the walk takes a newline that is not the record's own: a FORMAT == "GT" record whose sample
     columns are ONE byte shorter than S diploid calls (one haploid call and one two-digit allele), followed by an empty
     line — the byte at soff + 4 S - 1 is then the empty line's newline.  The merged record is kept, its fields do not
-    match "a|b\\t", the variable-width encoder finds the newline inside it: the call FAILS with HHGT_ERR_MALFORMED (flagged,
-    never a different matrix; the same rule as for records shorter than the hop's bound), and the plain scan
-    (hhgt_set_index_mode 0) decodes what the oracle decodes."""
+    match "a|b\\t", the variable-width encoder finds the newline inside it: the pass FAILS with HHGT_ERR_MALFORMED (flagged,
+    never a different matrix; the same rule as for records shorter than the hop's bound) — which is what the
+    asynchronous form reports; the synchronous call then scans every byte (as hhgt_set_index_mode 0 does from the start) and
+    decodes what the oracle decodes."""
     hdr, rec = wide_lines(S, 10)
     f = rec[4].split(b"\t")
     f[9 + 17] = b"1"
@@ -150,10 +151,19 @@ def test_newline_of_another_line_where_the_head_points(ctx, S):
         want = oracle.vcf_encode(t, S, region="chr7")
     except Exception:
         want = None
+    import torch
+    from haplohyped_varawareml_amd import device as dev
+    from tests.gpu_util import to_dev
     try:
         ctx.set_index_mode(2)
-        with pytest.raises(HhgtError, match="Error parsing VCF file"):
-            gpu_encode(ctx, t, S, region="chr7")
+        lay = dev.make_layout(S, 128, sc=64, vc=128)
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=ctx.device)
+        res = dev.EncodeResult(z(dev.layout_bytes(lay), torch.uint8), lay, z(lay.v_capacity, torch.int32), z(lay.v_capacity, torch.int32),
+                               z(lay.v_capacity, torch.uint8), z(lay.v_capacity, torch.uint8), 0, {})
+        with pytest.raises(HhgtError, match="Error parsing VCF file"):       # one pass (the asynchronous form): flagged
+            ctx.encode_text_async(to_dev(t), S, res, z(1, torch.int64), max_lines=200, region="chr7").wait()
+        if want is not None:                                                 # the synchronous call scans every byte then
+            assert_same_as_oracle(gpu_encode(ctx, t, S, region="chr7"), want)
         ctx.set_index_mode(0)
         if want is not None:
             assert_same_as_oracle(gpu_encode(ctx, t, S, region="chr7"), want)

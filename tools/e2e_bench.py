@@ -45,12 +45,12 @@ def make_shards(ctx, chroms, variants, samples, kind, level, tmpdir):
     return out
 
 
-def open_engine(ctx, device_inflate, threads, block_mb, files_ahead=1, fmt=None):
+def open_engine(ctx, device_inflate, threads, block_mb, files_ahead=1, fmt=None, expect_samples=0):
     from haplohyped_varawareml_amd import device as dev
     from haplohyped_varawareml_amd.ingest import Ingest
     t0 = time.perf_counter()
     ing = Ingest(ctx, fmt=fmt or dev.BLOSC2, device_inflate=device_inflate, n_threads=threads, block_bytes=block_mb << 20,
-                 files_ahead=files_ahead)
+                 files_ahead=files_ahead, expect_samples=expect_samples)
     return ing, time.perf_counter() - t0
 
 
@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--device-inflate", action="store_true", help="BGZF members inflated on the device (f-4)")
     ap.add_argument("--level", type=int, default=6, help="zlib level of the synthetic BGZF / gzip files")
     ap.add_argument("--files-ahead", type=int, default=1)
+    ap.add_argument("--no-expect", action="store_true", help="do not tell the engine the sample count at open (round 3's behaviour)")
     a = ap.parse_args()
     import torch  # noqa: F401
     from haplohyped_varawareml_amd import device as dev
@@ -96,7 +97,7 @@ def main():
     t0 = time.time()
     shards = make_shards(ctx, chroms, a.variants, a.samples, a.kind, a.level, d)
     prep = time.time() - t0
-    ing, t_open = open_engine(ctx, a.device_inflate, a.threads, a.block_mb, a.files_ahead)
+    ing, t_open = open_engine(ctx, a.device_inflate, a.threads, a.block_mb, a.files_ahead, expect_samples=0 if a.no_expect else a.samples)
     runs = [run(ing, shards) for _ in range(a.repeat)]
     ing.close()
     best = min(runs[1:] or runs, key=lambda r: r["seconds"])     # the first pass also pins the engine's staging memory
