@@ -1,6 +1,7 @@
 // api.hip — C ABI of libhhgt.so (see include/hhgt.h): context, orchestration of the kernel stages,
 // error reporting.  No CPU fallback anywhere: every compute entry point needs a HIP device.
 #include "common.h"
+#include <chrono>
 #include <vector>
 #include <stdarg.h>
 #include <stdio.h>
@@ -36,7 +37,12 @@ int DevBuf::ensure(size_t bytes)
         cap = 0;
     }
     size_t want = bytes + bytes / 8 + 256;
+    static const bool dbg = getenv("HHGT_ALLOC_DEBUG") != nullptr;   // development aid: late allocations stall every stream
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
+    if (dbg)
+        fprintf(stderr, "[alloc] %.3f ms  hipMalloc %zu took %.3f ms\n", std::chrono::duration<double>(t0.time_since_epoch()).count() * 1e3,
+                want, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     if (e != hipSuccess) {
         p = nullptr;
         hhgt_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));

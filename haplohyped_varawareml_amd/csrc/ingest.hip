@@ -83,6 +83,10 @@ struct PinnedBuf {   // grows on demand; pinned allocations are slow, so they on
         p = nullptr;
         cap = 0;
         const size_t want = n + n / 4 + 4096;
+        static const bool dbg = getenv("HHGT_ALLOC_DEBUG") != nullptr;
+        if (dbg)
+            fprintf(stderr, "[alloc] %.3f ms  hipHostMalloc %zu\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e3, want);
         if (hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault) != hipSuccess) {
             p = nullptr;
             hhgt_set_error("ingest: hipHostMalloc(%zu) failed", want);
@@ -122,7 +126,7 @@ struct Input {
 struct TextBuf {   // device-resident text block
     uint8_t *d = nullptr;
     size_t cap = 0;
-    hipEvent_t ready = nullptr;
+    hipEvent_t ready = nullptr, carry_done = nullptr;
     uint64_t nbytes = 0;
     Input *in = nullptr;
     bool first = false, last = false, end_of_inputs = false;
@@ -174,6 +178,7 @@ struct OutSlot {
 #define N_VAR 6
 #define N_DST 4
 #define N_OUT 5
+#define N_STG 4   // device-inflate staging slots: one per text buffer, so the source never waits for an inflate two blocks back
 
 }  // namespace
 
@@ -182,6 +187,11 @@ struct hhgt_ingest {
     hhgt_ingest_opts o;
     int device = 0;
     hipStream_t s_main = nullptr, s_copy = nullptr, s_inf = nullptr, s_out = nullptr;
+    // device inflate: the blocks alternate between s_inf and s_inf2 (one wave per member is latency-bound: the tail round of
+    // one block's launch overlaps the next block's), the few bytes behind a block's last newline move on s_carry
+    hipStream_t s_inf2 = nullptr, s_carry = nullptr;
+    uint64_t inf_blocks = 0;              // source thread only
+    hipEvent_t last_carry = nullptr;      // the latest carry copy queued (an event of some TextBuf), or null
     // inputs
     std::mutex in_mu;
     std::condition_variable in_cv;
@@ -198,7 +208,25 @@ struct hhgt_ingest {
     BQ<int> free_text;
     BQ<int> q_text;          // indices in order; -1 = end of inputs
     // device-inflate staging
-    Staging stg[2];
+    Staging stg[N_STG];
+    int stg_next = 0;            // source thread only: the slots go round across inputs
+    // member table of the stretch being cut (source thread only).  Raw arrays that only ever grow: a std::vector sized for the
+    // worst case (a member per 26 bytes: a million entries for a 25 MB stretch) zero-fills 20 MB per block — 2-5 ms of the
+    // source thread per 3 ms of device work (HHGT_INGEST_DEBUG=2: read_done -> scan_done)
+    struct MemberTab {
+        std::unique_ptr<uint64_t[]> c_off;
+        std::unique_ptr<uint32_t[]> c_len, isz, crc;
+        size_t cap = 0;
+        void ensure(size_t n)
+        {
+            if (n <= cap) return;
+            cap = n + n / 4;
+            c_off.reset(new uint64_t[cap]);
+            c_len.reset(new uint32_t[cap]);
+            isz.reset(new uint32_t[cap]);
+            crc.reset(new uint32_t[cap]);
+        }
+    } mtab;
     DevBuf crc_x2n;
     // encode state of an input (driver thread only).  Two sets, used alternately: the first blocks of input k+1 are
     // encoded while the last blocks of input k are still being harvested, so the GPU's queue does not drain at a
@@ -581,12 +609,13 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
     in->st.file_bytes = flen;
     in->is_bgzf = true;
     bool ok = true;
+    trace("src:file_open", (long long)flen);
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     inflateInit2(&zs, -15);
     std::vector<uint8_t> scratch(65536);
-    std::vector<uint64_t> c_off;
-    std::vector<uint32_t> c_len, isz, crc;
+    uint64_t *c_off = nullptr;
+    uint32_t *c_len = nullptr, *isz = nullptr, *crc = nullptr;
     auto host_inflate = [&](const uint8_t *base, size_t m, uint8_t *dst) -> bool {
         if (inflateReset(&zs) != Z_OK) return false;
         zs.next_in = const_cast<Bytef *>(base + c_off[m]);
@@ -609,7 +638,6 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
     int prev_ti = -1;
     uint64_t prev_cut = 0;
     bool first = true;
-    int sidx = 0;
     double ratio = 24.0;        // text bytes per file byte, refined as blocks go by
     // text budget of the first block: small when nothing is in flight (the GPU starts after ~1 ms of host work instead
     // of ~5), full size when earlier inputs still keep the device busy (a small launch fills a fraction of the chip)
@@ -621,9 +649,10 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
         ok = false;
     }
     while (ok && fpos < flen) {
-        Staging &sg = g->stg[sidx];
-        sidx ^= 1;
+        Staging &sg = g->stg[g->stg_next];
+        g->stg_next = (g->stg_next + 1) % N_STG;
         if (sg.used) hipEventSynchronize(sg.done);   // the inflate that read this staging slot two blocks ago
+        trace("src:staging_free");
         // stretch of the file to look at: what the budget should need, plus slack; at least one whole member
         uint64_t want = (uint64_t)((double)budget / ratio * 1.15) + (256u << 10);
         if (want > flen - fpos) want = flen - fpos;
@@ -657,14 +686,16 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
                 break;
             }
         }
+        trace("src:read_done", (long long)want);
         // member table of the stretch, cut at the text budget
         const size_t max_m = (size_t)(want / 26 + 2);
-        c_off.resize(max_m);
-        c_len.resize(max_m);
-        isz.resize(max_m);
-        crc.resize(max_m);
+        g->mtab.ensure(max_m);
+        c_off = g->mtab.c_off.get();
+        c_len = g->mtab.c_len.get();
+        isz = g->mtab.isz.get();
+        crc = g->mtab.crc.get();
         uint64_t nm64 = 0, used = 0;
-        const int rc = hhgt_bgzf_scan(sg.h.p, want, max_m, c_off.data(), c_len.data(), isz.data(), crc.data(), &nm64, &used);
+        const int rc = hhgt_bgzf_scan(sg.h.p, want, max_m, c_off, c_len, isz, crc, &nm64, &used);
         if (rc != HHGT_OK) {
             fail(g, rc, hhgt_last_error());
             ok = false;
@@ -689,6 +720,7 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
             break;
         }
         const bool last = fpos + consumed >= flen;
+        trace("src:scan_done", (long long)nm);
         if (first) {
             // header: leading members inflated on the host until the '#' lines are complete
             std::vector<uint8_t> head;
@@ -719,6 +751,7 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
                 break;
             }
         }
+        if (first) trace("src:header_done");
         // bytes behind the last newline move to the next block: the last member(s) are inflated here to find it
         uint64_t tail = 0;
         if (!last) {
@@ -752,6 +785,7 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
             break;
         }
         TextBuf &tb = g->text[(size_t)ti];
+        trace("src:took_text", (long long)ti);
         // staging layout: [compressed bytes | comp_off u64 | out_off u64 | comp_len u32 | isize u32 | crc u32]
         const size_t comp_bytes = ((size_t)consumed + 3) / 4 * 4 + 4;
         const size_t o_coff = (comp_bytes + 7) & ~(size_t)7, o_ooff = o_coff + nm * 8, o_clen = o_ooff + nm * 8,
@@ -780,10 +814,21 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
             oo += isz[i];
         }
         uint8_t *dd = sg.d.as<uint8_t>();
-        hipError_t e = hipMemcpyAsync(dd, sg.h.p, stg_bytes, hipMemcpyHostToDevice, g->s_inf);
-        if (e == hipSuccess && carry)
-            e = hipMemcpyAsync(tb.d, g->text[(size_t)prev_ti].d + prev_cut, carry, hipMemcpyDeviceToDevice, g->s_inf);
-        if (e == hipSuccess) e = hipMemsetAsync(tb.bad.p, 0, 8, g->s_inf);
+        hipStream_t si = (g->inf_blocks++ & 1) ? g->s_inf2 : g->s_inf;
+        hipError_t e = hipMemcpyAsync(dd, sg.h.p, stg_bytes, hipMemcpyHostToDevice, si);
+        // this block may write a text buffer an earlier carry copy still reads from (they run on their own stream)
+        if (e == hipSuccess && g->last_carry) e = hipStreamWaitEvent(si, g->last_carry, 0);
+        if (e == hipSuccess && carry) {
+            TextBuf &pb = g->text[(size_t)prev_ti];
+            e = hipStreamWaitEvent(g->s_carry, pb.ready, 0);   // the previous block's text is complete
+            if (e == hipSuccess) e = hipMemcpyAsync(tb.d, pb.d + prev_cut, carry, hipMemcpyDeviceToDevice, g->s_carry);
+            if (e == hipSuccess) e = hipEventRecord(tb.carry_done, g->s_carry);
+            g->last_carry = tb.carry_done;
+            // free_text is a FIFO of four, so a block never lands in the buffer of the one before it; if it ever does, the
+            // copy has to read the tail before the inflate overwrites it
+            if (e == hipSuccess && ti == prev_ti) e = hipStreamWaitEvent(si, tb.carry_done, 0);
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(tb.bad.p, 0, 8, si);
         if (e != hipSuccess) {
             fail(g, HHGT_ERR_HIP, "ingest: upload of compressed members failed");
             ok = false;
@@ -792,18 +837,19 @@ bool run_device_inflate_input(hhgt_ingest *g, Input *in)
         const int rc2 = launch_inflate(dd, comp_bytes, reinterpret_cast<const uint64_t *>(dd + o_coff),
                                        reinterpret_cast<const uint32_t *>(dd + o_clen), reinterpret_cast<const uint64_t *>(dd + o_ooff),
                                        reinterpret_cast<const uint32_t *>(dd + o_isz), nm, tb.d, tb.cap, tb.status.as<uint32_t>(),
-                                       reinterpret_cast<const uint32_t *>(dd + o_crc), g->crc_x2n.as<uint32_t>(), g->s_inf);
+                                       reinterpret_cast<const uint32_t *>(dd + o_crc), g->crc_x2n.as<uint32_t>(), si);
         if (rc2 != HHGT_OK) {
             fail(g, rc2, hhgt_last_error());
             ok = false;
             break;
         }
-        hipLaunchKernelGGL(k_count_bad_members, dim3((uint32_t)((nm + 255) / 256)), dim3(256), 0, g->s_inf, tb.status.as<uint32_t>(),
+        hipLaunchKernelGGL(k_count_bad_members, dim3((uint32_t)((nm + 255) / 256)), dim3(256), 0, si, tb.status.as<uint32_t>(),
                            (uint64_t)nm, tb.bad.as<unsigned long long>());
         *tb.h_bad = 0;
-        e = hipMemcpyAsync(tb.h_bad, tb.bad.p, 8, hipMemcpyDeviceToHost, g->s_inf);
-        if (e == hipSuccess) e = hipEventRecord(tb.ready, g->s_inf);
-        if (e == hipSuccess) e = hipEventRecord(sg.done, g->s_inf);
+        e = hipMemcpyAsync(tb.h_bad, tb.bad.p, 8, hipMemcpyDeviceToHost, si);
+        if (e == hipSuccess && carry) e = hipStreamWaitEvent(si, tb.carry_done, 0);
+        if (e == hipSuccess) e = hipEventRecord(tb.ready, si);
+        if (e == hipSuccess) e = hipEventRecord(sg.done, si);
         if (e != hipSuccess) {
             fail(g, HHGT_ERR_HIP, "ingest: device inflate launch failed");
             ok = false;
@@ -915,7 +961,7 @@ static bool size_input_state(hhgt_ingest *g, hhgt_ingest::InState *X, uint64_t S
     const size_t need_d = (size_t)(max_cols * X->n_sc * (X->chunk_nbytes + 32) + 64), need_off = (size_t)((max_cols * X->n_sc + 1) * 8);
     bool grow = false;
     for (auto &d : g->dst) grow = grow || d.d.cap < need_d || d.off.cap < need_off || d.h_off.cap < need_off;
-    for (auto &v : g->var) grow = grow || v.start.cap < (size_t)X->kept_per_block * 4 || v.ref.cap < (size_t)X->kept_per_block;
+    for (auto &v : g->var) grow = grow || v.start.cap < (size_t)X->kept_per_block * 4 + 16 || v.ref.cap < (size_t)X->kept_per_block + 4;
     if (grow) {
         int tmp;
         if (!at_open) {
@@ -930,9 +976,9 @@ static bool size_input_state(hhgt_ingest *g, hhgt_ingest::InState *X, uint64_t S
             G_TRY(d.h_off.ensure(need_off));
         }
         for (auto &v : g->var) {
-            G_TRY(v.start.ensure((size_t)X->kept_per_block * 4));
-            G_TRY(v.ref.ensure((size_t)X->kept_per_block));
-            G_TRY(v.alt.ensure((size_t)X->kept_per_block));
+            G_TRY(v.start.ensure((size_t)X->kept_per_block * 4 + 16));   // k_tables_to_host writes whole groups of four
+            G_TRY(v.ref.ensure((size_t)X->kept_per_block + 4));
+            G_TRY(v.alt.ensure((size_t)X->kept_per_block + 4));
         }
         if (!at_open) {
             for (int i = 0; i < N_DST; ++i) g->free_dst.push(i);
@@ -969,18 +1015,29 @@ bool begin_input(hhgt_ingest *g, Input *in, uint64_t block_bytes)
     return true;
 }
 
-// copy rows [a, b) of a ring table (ring of `cap` entries of `es` bytes) to host, in at most two pieces
-bool ring_d2h(hhgt_ingest *g, void *h, const void *d, uint64_t a, uint64_t b, uint64_t cap, size_t es)
+// rows [a, a + n) of the three variant tables (rings of `cap` entries) -> pinned host memory, written by the kernel itself over
+// the link.  One launch instead of three to six hipMemcpyAsync calls — and the runtime's copy path is kept out of the driver
+// thread: HHGT_INGEST_DEBUG=2 showed the first such copy above ~200 KB blocking the calling thread for as long as the encode
+// queued behind it on the stream ran (7 ms of a 60 ms first pass).  Thread i moves variants 4i .. 4i+3.
+__global__ void __launch_bounds__(256) k_tables_to_host(const uint32_t *__restrict__ t_start, const uint8_t *__restrict__ t_ref,
+                                                        const uint8_t *__restrict__ t_alt, uint64_t a, uint64_t n, uint64_t cap,
+                                                        uint32_t *__restrict__ h_start, uint32_t *__restrict__ h_ref,
+                                                        uint32_t *__restrict__ h_alt)
 {
-    uint64_t done = 0;
-    while (a + done < b) {
-        const uint64_t s = (a + done) % cap;
-        const uint64_t n = (b - a - done) < (cap - s) ? (b - a - done) : (cap - s);
-        G_HIP(hipMemcpyAsync(static_cast<uint8_t *>(h) + done * es, static_cast<const uint8_t *>(d) + s * es, (size_t)(n * es),
-                             hipMemcpyDeviceToHost, g->s_main));
-        done += n;
-    }
-    return true;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x, v0 = i * 4;
+    if (v0 >= n) return;
+    uint32_t st[4] = {0, 0, 0, 0}, r = 0, al = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (v0 + k < n) {
+            const uint64_t s = (a + v0 + k) % cap;
+            st[k] = t_start[s];
+            r |= (uint32_t)t_ref[s] << (8 * k);
+            al |= (uint32_t)t_alt[s] << (8 * k);
+        }
+    *reinterpret_cast<uint4 *>(h_start + v0) = make_uint4(st[0], st[1], st[2], st[3]);   // slots hold kept_per_block + 4 entries
+    h_ref[i] = r;
+    h_alt[i] = al;
 }
 
 bool get_event(hhgt_ingest *g, hipEvent_t *ev)
@@ -1103,9 +1160,14 @@ bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
         trace("drv:var_slot");
         VarSlot &vs = g->var[(size_t)v.var_slot];
         const uint64_t cap = X->lay.v_capacity;
-        if (!ring_d2h(g, vs.start.p, X->t_start.p, a, b, cap, 4) || !ring_d2h(g, vs.ref.p, X->t_ref.p, a, b, cap, 1) ||
-            !ring_d2h(g, vs.alt.p, X->t_alt.p, a, b, cap, 1))
-            return false;
+        if (b > a) {
+            const uint64_t nt = (b - a + 3) / 4;
+            hipLaunchKernelGGL(k_tables_to_host, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, g->s_main, X->t_start.as<uint32_t>(),
+                               X->t_ref.as<uint8_t>(), X->t_alt.as<uint8_t>(), a, b - a, cap, reinterpret_cast<uint32_t *>(vs.start.p),
+                               reinterpret_cast<uint32_t *>(vs.ref.p), reinterpret_cast<uint32_t *>(vs.alt.p));
+            G_HIP(hipGetLastError());
+        }
+        trace("drv:tables_queued", (long long)(b - a));
         for (uint64_t i = 0; i < rec.stats.n_chrom_runs; ++i) {
             const std::string name(rec.run_names[i], strnlen(rec.run_names[i], 31));
             if (name == in->last_run) continue;   // the block continues the previous block's contig
@@ -1117,6 +1179,7 @@ bool harvest_body(hhgt_ingest *g, hhgt_ingest::Res &r)
         }
         G_HIP(hipEventRecord(v.ev, g->s_main));
         g->q_ship.push(v);
+        trace("drv:var_queued");
     }
     if (in->S) {
         const uint64_t done = b / (uint64_t)g->o.vc;
@@ -1328,6 +1391,8 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hip(hipStreamCreateWithPriority(&g->s_copy, hipStreamNonBlocking, prio_hi), "stream");
     hip(hipStreamCreateWithFlags(&g->s_inf, hipStreamNonBlocking), "stream");
+    hip(hipStreamCreateWithFlags(&g->s_inf2, hipStreamNonBlocking), "stream");
+    hip(hipStreamCreateWithFlags(&g->s_carry, hipStreamNonBlocking), "stream");
     hip(hipStreamCreateWithPriority(&g->s_out, hipStreamNonBlocking, prio_hi), "stream");
     const bool dev = g->o.device_inflate != 0;
     const uint64_t bb_host = g->o.block_bytes ? g->o.block_bytes : (64ull << 20);
@@ -1339,6 +1404,7 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
         hip(hipMalloc(reinterpret_cast<void **>(&tb.d), (size_t)bb + 256), "hipMalloc(text block)");
         tb.cap = rc == HHGT_OK ? (size_t)bb + 256 : 0;
         hip(hipEventCreateWithFlags(&tb.ready, hipEventDisableTiming), "event");
+        hip(hipEventCreateWithFlags(&tb.carry_done, hipEventDisableTiming), "event");
         hip(hipHostMalloc(reinterpret_cast<void **>(&tb.h_bad), 8, hipHostMallocDefault), "hipHostMalloc");
         if (rc == HHGT_OK) g->free_text.push((int)i);
     }
@@ -1384,7 +1450,10 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
         if (ok && dev) {
             const uint64_t want = (uint64_t)((double)bb_dev / 24.0 * 1.15) + (256u << 10);
             const size_t tab_room = (size_t)(want / 26 + 2) * 28 + 64;
-            for (auto &sg : g->stg) ok = ok && sg.h.ensure((size_t)want + 64 + tab_room) == HHGT_OK;
+            for (auto &sg : g->stg) ok = ok && sg.h.ensure((size_t)want + 64 + tab_room) == HHGT_OK && sg.d.ensure((size_t)want + 64 + tab_room) == HHGT_OK;
+            // per text buffer: a status word per member (files written by bgzip hold ~64 KB of text per member; four times as
+            // many fit before these grow inside a pass — a hipFree there waits for the device to drain)
+            for (auto &tb : g->text) ok = ok && tb.status.ensure((size_t)(bb_dev / 16384 + 64) * 4) == HHGT_OK && tb.bad.ensure(8) == HHGT_OK;
         }
         if (ok && g->o.device_inflate != 1) hhgt_reader_prewarm(bb_host, 6 * ((g->o.files_ahead > 0 ? g->o.files_ahead : 1) + 1));
         if (ok && S > 0) {
@@ -1410,7 +1479,7 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
             hhgt_ingest::InState &X0 = g->ist[0];
             DstSlot &d0 = g->dst[0];
             uint8_t *h8 = d0.h_off.p;   // pinned, >= 16 bytes
-            for (hipStream_t st : {g->s_main, g->s_copy, g->s_inf, g->s_out}) {
+            for (hipStream_t st : {g->s_main, g->s_copy, g->s_inf, g->s_inf2, g->s_carry, g->s_out}) {
                 ok = ok && hipMemcpyAsync(X0.cursor.p, h8, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
                      hipMemcpyAsync(h8 + 8, X0.cursor.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
                      hipMemsetAsync(X0.cursor.p, 0, 8, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
@@ -1572,10 +1641,11 @@ extern "C" void hhgt_ingest_close(hhgt_ingest *g)
     if (trace_level() >= 2) {
         std::lock_guard<std::mutex> lk(g_trace_mu);
         const double t0 = g_trace.empty() ? 0 : g_trace[0].t;
+        fprintf(stderr, "[trace] t0 = %.3f ms (steady clock; HHGT_ALLOC_DEBUG lines carry the same clock)\n", t0 * 1e3);
         for (auto &r : g_trace) fprintf(stderr, "[trace] %9.3f ms  %-20s %lld %lld\n", (r.t - t0) * 1e3, r.tag, r.a, r.b);
         g_trace.clear();
     }
-    for (hipStream_t s : {g->s_main, g->s_copy, g->s_inf, g->s_out})
+    for (hipStream_t s : {g->s_main, g->s_copy, g->s_inf, g->s_inf2, g->s_carry, g->s_out})
         if (s) {
             hipStreamSynchronize(s);
             hipStreamDestroy(s);
@@ -1583,6 +1653,7 @@ extern "C" void hhgt_ingest_close(hhgt_ingest *g)
     for (auto &tb : g->text) {
         if (tb.d) hipFree(tb.d);
         if (tb.ready) hipEventDestroy(tb.ready);
+        if (tb.carry_done) hipEventDestroy(tb.carry_done);
         if (tb.h_bad) hipHostFree(tb.h_bad);
         tb.status.release();
         tb.bad.release();

@@ -3,6 +3,7 @@ chunks and variant tables out, every stage (host inflate / upload / encode / com
 concurrently inside libhhgt.  Replaces the per-(donor, chromosome) loop body of
 /root/reference/src/haplohyped/vcf_to_h5.py:79-140 for all samples of a file at once."""
 import ctypes as C
+import gc
 from collections import namedtuple
 
 import numpy as np
@@ -126,24 +127,33 @@ class Ingest:
     def events(self):
         """yields Header / Variants / Columns / InputEnd in order; the numpy views are valid until the next event"""
         ev = IngestEvent()
-        while True:
-            check(self.L.hhgt_ingest_next(self.h, C.byref(ev)))
-            k = ev.kind
-            if k == EV_END:
-                return
-            if k == EV_HEADER:
-                yield Header(ev.input, C.string_at(ev.header, ev.header_bytes), int(ev.n_samples))
-            elif k == EV_VARIANTS:
-                names = _view(ev.run_names, ev.n_runs * 32, np.uint8).reshape(-1, 32)
-                first = _view(ev.run_first, ev.n_runs, np.uint64)
-                runs = [(int(first[i]), bytes(names[i]).split(b"\0")[0].decode()) for i in range(ev.n_runs)]
-                yield Variants(ev.input, int(ev.first_variant), _view(ev.start, ev.n_variants, np.uint32),
-                               _view(ev.ref, ev.n_variants, np.uint8), _view(ev.alt, ev.n_variants, np.uint8), runs)
-            elif k == EV_COLUMNS:
-                yield Columns(ev.input, int(ev.first_col), int(ev.n_cols), _view(ev.framed, ev.framed_bytes, np.uint8),
-                              _view(ev.chunk_off, ev.n_chunks + 1, np.uint64), int(ev.raw_bytes))
-            elif k == EV_INPUT_END:
-                yield InputEnd(ev.input, ev.stats.asdict())
+        # everything alive now (torch, numpy: some 10^5 container objects) moves to the permanent generation for the length
+        # of the loop: a full collection while the engine's out slots wait on this thread costs 20-40 ms otherwise (measured:
+        # one such pause per 3 M-variant pass, 10 % of it)
+        ours = gc.get_freeze_count() == 0      # a caller that froze already keeps their freeze
+        gc.freeze()
+        try:
+            while True:
+                check(self.L.hhgt_ingest_next(self.h, C.byref(ev)))
+                k = ev.kind
+                if k == EV_END:
+                    return
+                if k == EV_HEADER:
+                    yield Header(ev.input, C.string_at(ev.header, ev.header_bytes), int(ev.n_samples))
+                elif k == EV_VARIANTS:
+                    names = _view(ev.run_names, ev.n_runs * 32, np.uint8).reshape(-1, 32)
+                    first = _view(ev.run_first, ev.n_runs, np.uint64)
+                    runs = [(int(first[i]), bytes(names[i]).split(b"\0")[0].decode()) for i in range(ev.n_runs)]
+                    yield Variants(ev.input, int(ev.first_variant), _view(ev.start, ev.n_variants, np.uint32),
+                                   _view(ev.ref, ev.n_variants, np.uint8), _view(ev.alt, ev.n_variants, np.uint8), runs)
+                elif k == EV_COLUMNS:
+                    yield Columns(ev.input, int(ev.first_col), int(ev.n_cols), _view(ev.framed, ev.framed_bytes, np.uint8),
+                                  _view(ev.chunk_off, ev.n_chunks + 1, np.uint64), int(ev.raw_bytes))
+                elif k == EV_INPUT_END:
+                    yield InputEnd(ev.input, ev.stats.asdict())
+        finally:
+            if ours:
+                gc.unfreeze()
 
     def close(self):
         if getattr(self, "h", None):

@@ -89,6 +89,16 @@ def main():
     ap.add_argument("--files-ahead", type=int, default=1)
     ap.add_argument("--no-expect", action="store_true", help="do not tell the engine the sample count at open (round 3's behaviour)")
     a = ap.parse_args()
+    if os.environ.get("HHGT_GC_DEBUG"):     # collector pauses of the consuming thread (the engine's out slots wait on it)
+        import gc
+        t_gc = [0.0]
+
+        def on_gc(phase, info):
+            if phase == "start":
+                t_gc[0] = time.perf_counter()
+            elif time.perf_counter() - t_gc[0] > 1e-3:
+                print(f"[gc] generation {info['generation']}: {(time.perf_counter() - t_gc[0]) * 1e3:.1f} ms", file=sys.stderr)
+        gc.callbacks.append(on_gc)
     import torch  # noqa: F401
     from haplohyped_varawareml_amd import device as dev
     ctx = dev.Context(0)
