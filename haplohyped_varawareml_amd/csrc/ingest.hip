@@ -279,6 +279,14 @@ int trace_level()
     static const int lv = getenv("HHGT_INGEST_DEBUG") ? atoi(getenv("HHGT_INGEST_DEBUG")) : 0;
     return lv;
 }
+// events a host thread waits on: the waiter sleeps (hipEventBlockingSync) instead of spinning — the driver spends ~90 % of a
+// host-inflated pass inside such a wait and the shipper and the source most of the rest: up to three of the (16 granted) CPUs
+// the reader's inflate threads are short of.  HHGT_INGEST_SPIN=1 restores the spinning waits.
+unsigned wait_event_flags()
+{
+    static const bool spin = getenv("HHGT_INGEST_SPIN") && atoi(getenv("HHGT_INGEST_SPIN")) != 0;
+    return hipEventDisableTiming | (spin ? 0u : (unsigned)hipEventBlockingSync);
+}
 void trace(const char *tag, long long a = 0, long long b = 0)
 {
     if (trace_level() < 2) return;
@@ -419,7 +427,16 @@ bool open_reader(hhgt_ingest *g, Input *in)
 {
     if (in->rd || in->kind != 0) return true;
     const uint64_t bb = g->o.block_bytes ? g->o.block_bytes : (64ull << 20);
-    G_TRY(hhgt_reader_open(in->path.c_str(), bb, g->o.n_threads, 6, &in->rd));
+    // default: the granted CPUs less two — the engine's own threads and the consumer need the rest, and under a cgroup quota a
+    // process that asks for more than its share is throttled as a whole (measured on 16 granted CPUs: 14 inflate threads 5.1 M
+    // variants/s, steadily; 16: 4.6 M; 13: 4.8 M)
+    int nt = g->o.n_threads;
+    if (nt <= 0 && !getenv("HHGT_READER_THREADS")) {
+        const int eff = hhgt_effective_cpus();
+        nt = eff >= 6 ? eff - 2 : eff;
+        if (nt > 96) nt = 96;
+    }
+    G_TRY(hhgt_reader_open(in->path.c_str(), bb, nt, 6, &in->rd));
     in->is_bgzf = hhgt_reader_is_bgzf(in->rd) != 0;
     return true;
 }
@@ -447,8 +464,8 @@ bool run_reader_input(hhgt_ingest *g, Input *in)
 {
     if (!open_reader(g, in)) return false;
     hipEvent_t cev[2] = {nullptr, nullptr};
-    G_HIP(hipEventCreateWithFlags(&cev[0], hipEventDisableTiming));
-    G_HIP(hipEventCreateWithFlags(&cev[1], hipEventDisableTiming));
+    G_HIP(hipEventCreateWithFlags(&cev[0], wait_event_flags()));
+    G_HIP(hipEventCreateWithFlags(&cev[1], wait_event_flags()));
     int prev_tok = -1, k = 0;
     bool first = true, ok = true;
     for (;;) {
@@ -1284,7 +1301,7 @@ void ship_main(hhgt_ingest *g)
 {
     hipSetDevice(g->device);
     hipEvent_t cev = nullptr;
-    hipEventCreateWithFlags(&cev, hipEventDisableTiming);
+    hipEventCreateWithFlags(&cev, wait_event_flags());
     for (;;) {
         Batch b;
         if (!g->q_ship.pop(b)) break;
@@ -1408,17 +1425,17 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
         hip(hipHostMalloc(reinterpret_cast<void **>(&tb.h_bad), 8, hipHostMallocDefault), "hipHostMalloc");
         if (rc == HHGT_OK) g->free_text.push((int)i);
     }
-    for (auto &s : g->stg) hip(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event");
+    for (auto &s : g->stg) hip(hipEventCreateWithFlags(&s.done, wait_event_flags()), "event");
     for (int i = 0; i < N_RES && rc == HHGT_OK; ++i) {
         hip(hipHostMalloc(reinterpret_cast<void **>(&g->res[i].rec), sizeof(hhgt_encode_result), hipHostMallocDefault), "hipHostMalloc");
-        hip(hipEventCreateWithFlags(&g->res[i].ev, hipEventDisableTiming), "event");
+        hip(hipEventCreateWithFlags(&g->res[i].ev, wait_event_flags()), "event");
     }
     for (int i = 0; i < N_VAR; ++i) g->free_var.push(i);
     for (int i = 0; i < N_DST; ++i) g->free_dst.push(i);
     for (int i = 0; i < N_OUT; ++i) g->free_out.push(i);
     for (int i = 0; i < N_VAR + N_DST + 4 && rc == HHGT_OK; ++i) {
         hipEvent_t e = nullptr;
-        hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+        hip(hipEventCreateWithFlags(&e, wait_event_flags()), "event");
         if (e) {
             g->batch_events.push_back(e);
             g->free_ev.push(e);
