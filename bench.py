@@ -430,7 +430,7 @@ def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce
             return 3 * h0.numel() / (time.perf_counter() - t) / 1e9
 
         link = h2d_rate()
-        n_threads = sharding.reader_threads(host["n_threads"]) if world > 1 else 0      # N ranks: each its share of the granted CPUs (0: the engine's default, granted - 2)
+        n_threads = host["n_threads"] if world > 1 else 0      # N ranks: each its share of the granted CPUs
 
         def run(jobs, device_inflate, want_v, passes=2):
             out = []
@@ -482,7 +482,7 @@ def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce
                          f"{int(e2e_bytes_all / 1e9)} GB of text in {file_bytes_all / 1e6:.0f} MB of files in /dev/shm) -> framed chunks in "
                          f"pinned host memory; second (steady) pass, the first (engine cold) beside it; no best-of",
                "file_bytes": int(file_bytes_all), "prep_seconds": prep, "host_cpus_granted": host["granted"],
-               "reader_threads_per_rank": n_threads or sharding.reader_threads(host["n_threads"]), "numa_node": host["numa_node"],
+               "reader_threads_per_rank": n_threads or host["n_threads"], "numa_node": host["numa_node"],
                "default_policy": "device_inflate='auto' (pipeline.stream_files, the converter): BGZF files that compress >= 2:1 "
                                  "take the device inflater — the leg below named device_inflate IS that default; host "
                                  "(device_inflate=False / HHGT_DEVICE_INFLATE=0) is the north star's design"}

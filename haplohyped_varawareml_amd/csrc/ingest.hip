@@ -427,16 +427,7 @@ bool open_reader(hhgt_ingest *g, Input *in)
 {
     if (in->rd || in->kind != 0) return true;
     const uint64_t bb = g->o.block_bytes ? g->o.block_bytes : (64ull << 20);
-    // default: the granted CPUs less two — the engine's own threads and the consumer need the rest, and under a cgroup quota a
-    // process that asks for more than its share is throttled as a whole (measured on 16 granted CPUs: 14 inflate threads 5.1 M
-    // variants/s, steadily; 16: 4.6 M; 13: 4.8 M)
-    int nt = g->o.n_threads;
-    if (nt <= 0 && !getenv("HHGT_READER_THREADS")) {
-        const int eff = hhgt_effective_cpus();
-        nt = eff >= 6 ? eff - 2 : eff;
-        if (nt > 96) nt = 96;
-    }
-    G_TRY(hhgt_reader_open(in->path.c_str(), bb, nt, 6, &in->rd));
+    G_TRY(hhgt_reader_open(in->path.c_str(), bb, g->o.n_threads, 6, &in->rd));
     in->is_bgzf = hhgt_reader_is_bgzf(in->rd) != 0;
     return true;
 }

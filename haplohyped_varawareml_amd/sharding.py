@@ -131,14 +131,6 @@ def effective_cpus():
         return max(len(os.sched_getaffinity(0)), 1)
 
 
-def reader_threads(budget):
-    """inflate threads for an ingest engine whose rank may use `budget` CPUs: two are left to the engine's own threads and the
-    consumer (the native default does the same with the granted CPUs: csrc/ingest.hip open_reader) — under a cgroup quota asking
-    for every CPU gets the whole process throttled"""
-    budget = max(int(budget), 1)
-    return budget - 2 if budget >= 6 else budget
-
-
 def pin_rank(rank, world, device=None, cores=None, devices=None):
     """Pins the calling process to its share of the host CPUs (see partition_cpus) and returns
     dict(cpus, n_threads, numa_node, granted).  The thread budget of a rank is its share of what the host GRANTS

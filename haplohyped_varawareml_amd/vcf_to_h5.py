@@ -110,7 +110,7 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
         make_ctx = Context
     # this rank's share of the host: its reader threads (the engine starts `n_threads` per open file) stay on the CPUs of
     # its GPU's NUMA node and the N ranks of a node do not oversubscribe it (N x --cores threads before)
-    from .sharding import pin_rank, reader_threads
+    from .sharding import pin_rank
     devices = None
     if real_device:
         try:
@@ -151,7 +151,7 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
 
     try:
         if jobs:
-            stream_fn(ctx, jobs, sc=writer.meta["sc"], vc=writer.meta["vc"], n_threads=reader_threads(host["n_threads"]), fmt=BLOSC1,
+            stream_fn(ctx, jobs, sc=writer.meta["sc"], vc=writer.meta["vc"], n_threads=host["n_threads"], fmt=BLOSC1,
                       on_header=on_header, on_variants=lambda i, a, b, c: writer.add_variants(a, b, c),
                       on_columns=lambda i, g, n, framed: writer.add_chunks(framed[0], framed[1], g.numel()), on_end=on_end)
         writer.close()

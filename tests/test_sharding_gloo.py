@@ -95,8 +95,3 @@ def test_pin_rank_takes_the_rank_to_device_list(monkeypatch):
     assert asked[0] == 1 and asked[1:] == [0, 1, 0, 1]
     assert r["n_threads"] >= 1
 
-
-def test_reader_threads_leave_two_cpus_to_the_engine():
-    from haplohyped_varawareml_amd.sharding import reader_threads
-    assert reader_threads(16) == 14 and reader_threads(6) == 4      # the engine's three threads and the consumer take the rest
-    assert reader_threads(5) == 5 and reader_threads(1) == 1 and reader_threads(0) == 1   # small shares are not cut to nothing
