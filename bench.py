@@ -522,11 +522,15 @@ def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce
 # ---------------------------------------------------------------------------------------------------------------
 # the other GPU configurations of BASELINE.json (configs[1] = C2, configs[3] = C4) as legs of the same line
 # ---------------------------------------------------------------------------------------------------------------
-def config_leg(ctx, which, variants=None, steps=3, check=True):
-    """One pass of the hot path (encode -> pad -> compress, bit-plane intermediate, single stream, text resident in HBM) over
-    C2 = synthetic chr22, 50 000 variants x 1000 samples, biallelic phased, or
+def config_leg(ctx, which, variants=None, steps=3, check=True, streams=None):
+    """One pass of the hot path (encode -> pad -> compress, bit-plane intermediate, text resident in HBM) over
+    C2 = synthetic chr22, 50 000 variants x 1000 samples, biallelic phased (one piece of text, single stream), or
     C4 = 500 000 variants x 5000 samples with multiallelic records (dropped by the reference's isSNP filter), ./. and .|1
-         calls, '/' separators and GT:DP columns; its text (11.5 GB) is rendered and encoded in pieces below 4 GiB.
+         calls, '/' separators and GT:DP columns; its text (11.5 GB) is rendered and encoded in pieces below 4 GiB.  With
+         `streams` (the library's encode / compress pair; development, HHGT_BENCH_C4_PIPED=1) the pass is piped the way the ingest
+         engine pipes a file: piece k + 1 is queued, then the result record of piece k is read and the chunk columns it completed are
+         compressed on the second stream while piece k + 1 is encoded on the first (the same chunks, in the same dst) — measured
+         slower than the single-stream pass the line reports.  `stages_ms`: one single-stream pass.
     Checked after the timed passes: kept counts against the generator's table, every chunk decoded on the GPU against the
     expanded planes, sampled variants against the generator's call rule, one chunk through the CPU oracle."""
     import numpy as np
@@ -543,7 +547,7 @@ def config_leg(ctx, which, variants=None, steps=3, check=True):
         S, V, contig, seed = 5000, variants or 500_000, "chr4", 4
         tab = synth.mixed_table(seed, V, S)
         kept = np.nonzero(tab["kept"])[0]
-        pieces, step_v = [], 100_000
+        pieces, step_v = [], int(os.environ.get("HHGT_BENCH_C4_PIECE", "100000"))   # (development: variants per piece of text)
         for a in range(0, V, step_v):
             sub = {k: (v[a:a + step_v] if isinstance(v, np.ndarray) and len(v) == V else v) for k, v in tab.items()}
             pieces.append(ctx.synth_mixed(contig, sub, S, seed=seed, v_first=a, with_header=(a == 0))[0])
@@ -555,40 +559,97 @@ def config_leg(ctx, which, variants=None, steps=3, check=True):
                            z(dev.planes_bytes(lay), torch.uint8))
     chunk_nbytes = lay.sc * lay.vc * 2
     n_chunks = dev.layout_bytes(lay) // chunk_nbytes
-    dst = torch.empty(n_chunks * (chunk_nbytes + 32), dtype=torch.uint8, device=d)
-    off = z(n_chunks + 1, torch.int64)
+    n_cols = cap // lay.vc
+    per_col = n_chunks // n_cols                     # chunks of one chunk column
+    slot = chunk_nbytes + 32
+    dst = torch.empty(n_chunks * slot, dtype=torch.uint8, device=d)
+    # a batch of columns [c0, c1) frames into dst[c0 * per_col * slot ...] with its own offset table (per_col * (c1 - c0) + 1 entries
+    # at off_all[c0 * per_col + batch index]); a single-stream pass is one batch
+    off_all = z(n_chunks + len(pieces) + 1, torch.int64)
     cursor = z(1, torch.int64)
     pend = [dev.PendingEncode() for _ in pieces]
+    piped = streams is not None and len(pieces) > 1
+    batches = []                                     # (c0, c1, batch index) of the last pass
+
+    def compress_cols(c0, c1, bi):
+        ctx.compress_planes(res, col0=c0, n_cols=c1 - c0, fmt=dev.BLOSC2, dst=dst[c0 * per_col * slot:c1 * per_col * slot],
+                            chunk_off=off_all[c0 * per_col + bi:c1 * per_col + bi + 1], sync=False)
+        batches.append((c0, c1, bi))
+
+    def encode(k):
+        t = pieces[k]
+        ctx.encode_text_planes_async(t, S, res, cursor, max_lines=t.numel() // (2 * S + 17) + 64, region=contig, pending=pend[k])
 
     def one_pass():
+        del batches[:]
         cursor.zero_()
-        for t, p in zip(pieces, pend):
-            ctx.encode_text_planes_async(t, S, res, cursor, max_lines=t.numel() // (2 * S + 17) + 64, region=contig, pending=p)
+        for k in range(len(pieces)):
+            encode(k)
         ctx.pad_tail_planes_cursor(res, cursor)
-        ctx.compress_planes(res, fmt=dev.BLOSC2, dst=dst, chunk_off=off, sync=False)
+        compress_cols(0, n_cols, 0)
 
+    def one_pass_piped():
+        s_enc, s_cmp = streams[:2]
+        del batches[:]
+        done = 0
+        main = torch.cuda.current_stream()
+        s_enc.wait_stream(main)
+        s_cmp.wait_stream(main)
+        with torch.cuda.stream(s_enc):
+            cursor.zero_()
+            encode(0)
+        for k in range(1, len(pieces) + 1):
+            with torch.cuda.stream(s_enc):
+                if k < len(pieces):
+                    encode(k)                                   # queued before piece k - 1's record is read
+                else:
+                    ctx.pad_tail_planes_cursor(res, cursor)
+                    tail = s_enc.record_event()
+            rec = pend[k - 1].wait()                            # (the host waits; the device has piece k to work on)
+            c1 = n_cols if k == len(pieces) else int(rec.cursor_after) // lay.vc
+            if c1 > done:
+                with torch.cuda.stream(s_cmp):
+                    s_cmp.wait_event(tail if k == len(pieces) else pend[k - 1].event)
+                    compress_cols(done, c1, k - 1)
+                done = c1
+        main.wait_stream(s_enc)
+        main.wait_stream(s_cmp)
+
+    run = one_pass_piped if piped else one_pass
     one_pass()
     torch.cuda.synchronize()
-    ctx.profile(True)
+    ctx.profile(True)                                # stage times: one single-stream pass (events around every stage of one chain)
     ctx.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_pass()
+    one_pass()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
     stages = ctx.profile_read()
     ctx.profile(False)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
     recs = [p.wait() for p in pend]
     if not check:   # development builds whose output is not valid (timing only): --only-config ... --no-check
-        return {"value": n_kept / dt, "ms_per_pass": dt * 1e3, "stages_ms": {k: v["ms"] / steps for k, v in stages.items()},
+        return {"value": n_kept / dt, "ms_per_pass": dt * 1e3, "stages_ms": {k: v["ms"] for k, v in stages.items()},
                 "compression_ratio": 0.0, "checked": "nothing (--no-check)"}
     if int(cursor.item()) != n_kept or sum(r.stats.n_records for r in recs) != V or any(r.reserved for r in recs):
         raise AssertionError(f"{which}: kept {int(cursor.item())} of {n_kept} expected, records {sum(r.stats.n_records for r in recs)} of {V}")
     G = ctx.planes_expand(res)
-    back, bad = ctx.decompress(dst, off, n_chunks, chunk_nbytes, typesize=2, blocksize=8192)
-    if bad or not torch.equal(back, G):
-        raise AssertionError(f"{which}: decoded chunks differ from the expanded planes ({bad} chunks flagged)")
-    del back
+    comp = 0
+    col_bytes = per_col * chunk_nbytes
+    for c0, c1, bi in batches:                       # every batch of the LAST timed pass, against the expanded planes
+        off = off_all[c0 * per_col + bi:c1 * per_col + bi + 1]
+        back, bad = ctx.decompress(dst[c0 * per_col * slot:c1 * per_col * slot], off, (c1 - c0) * per_col, chunk_nbytes, typesize=2,
+                                   blocksize=8192)
+        if bad or not torch.equal(back, G[c0 * col_bytes:c1 * col_bytes]):
+            raise AssertionError(f"{which}: decoded chunks of columns {c0}..{c1} differ from the expanded planes ({bad} chunks flagged)")
+        comp += int(off[-1].item())
+        del back
+    if sorted(b[:2] for b in batches)[0][0] != 0 or sum(c1 - c0 for c0, c1, _ in batches) != n_cols:
+        raise AssertionError(f"{which}: the batches {batches} do not cover the {n_cols} chunk columns")
     rng = np.random.default_rng(7)
     pick = np.sort(rng.choice(n_kept, min(n_kept, 512), replace=False))
     g = G.view(torch.int8).view(cap // lay.vc, -(-S // lay.sc), lay.sc, lay.vc, 2)
@@ -600,11 +661,11 @@ def config_leg(ctx, which, variants=None, steps=3, check=True):
         want = synth.mixed_expected_G(seed, tab, S, kept[pick])
     if not np.array_equal(got, want):
         raise AssertionError(f"{which}: sampled variants differ from the generator's calls")
-    k = n_chunks // 2
-    o2 = off[k:k + 2].cpu().numpy()
+    c0, c1, bi = batches[len(batches) // 2]          # one chunk through the CPU oracle
+    k = ((c0 + c1) // 2) * per_col + per_col // 2
+    o2 = off_all[k + bi:k + bi + 2].cpu().numpy() + c0 * per_col * slot
     if not np.array_equal(oracle.blosc_decompress(dst[int(o2[0]):int(o2[1])].cpu().numpy()), G[k * chunk_nbytes:(k + 1) * chunk_nbytes].cpu().numpy()):
         raise AssertionError(f"{which}: chunk {k} does not decode (oracle) to the matrix bytes")
-    comp = int(off[-1].item())
     n_missing = int((G.view(torch.int8) == -9).sum().item())
     # nonzero bytes per 4096-variant plane: what the bit-plane coders walk (more than 636: the byte-wise kernel's)
     per_plane = (G.view(-1, lay.vc // 4096, 4096, 2) != 0).sum(dim=2).reshape(-1).float()
@@ -617,9 +678,9 @@ def config_leg(ctx, which, variants=None, steps=3, check=True):
            "missing_calls": n_missing, "compression_ratio": n_kept * 2 * S / max(comp, 1),
            "nonzero_bytes_per_plane": {"mean": float(per_plane.mean().item()), "max": float(per_plane.max().item()),
                                        "planes_left_to_the_byte_wise_coder": dense},
-           "stages_ms": {k_: v["ms"] / steps for k_, v in stages.items()},
+           "stages_ms": {k_: v["ms"] for k_, v in stages.items()},
            "checked": f"{n_chunks} chunks decoded on the GPU, {len(pick)} variants against the generator, 1 chunk through the oracle",
-           "streams": 1}
+           "streams": 2 if piped else 1, "batches": len(batches)}
     del G, res, dst, pieces
     torch.cuda.empty_cache()
     return out
@@ -659,7 +720,11 @@ def main():
     ctx.set_clevel(args.clevel)
     if args.only_config:
         name, _, nv = args.only_config.partition(":")
-        print(json.dumps(config_leg(ctx, name, int(nv) if nv else None, check=not args.no_check)))
+        # (HHGT_BENCH_C4_PIPED=1: C4's pieces piped over the stream pair — measured 13.7 against 12.5 ms: five pieces are all fill and
+        # drain, and smaller ones are launch-bound: 17.8 ms with 10, 30 ms with 20)
+        piped = os.environ.get("HHGT_BENCH_C4_PIPED") == "1"
+        print(json.dumps(config_leg(ctx, name, int(nv) if nv else None, check=not args.no_check,
+                                    streams=(ctx.create_stream("encode"), ctx.create_stream("compress")) if piped else None)))
         return
     S = args.samples
     shards = build_shards(ctx, args, rank, world)

@@ -115,7 +115,7 @@ extern "C" void hhgt_ctx_destroy(hhgt_ctx *c)
                       &c->counters, &c->cursor, &c->result, &c->dec_bad, &c->oh_ovl, &c->oh_lut, &c->crc_x2n};
     for (DevBuf *b : bufs) b->release();
     for (auto &w : c->cw) {
-        DevBuf *wb[] = {&w.lz_scratch, &w.lz_csize, &w.fr_bsize, &w.fr_csize, &w.fr_flags, &w.fr_state};
+        DevBuf *wb[] = {&w.lz_scratch, &w.lz_csize, &w.lz_flags, &w.fr_bsize, &w.fr_csize, &w.fr_flags, &w.fr_state};
         for (DevBuf *b : wb) b->release();
         if (w.lz_done) hipEventDestroy(w.lz_done);
         if (w.fr_done) hipEventDestroy(w.fr_done);
@@ -840,8 +840,14 @@ static int compress_impl(hhgt_ctx *c, const void *d_src, const void *d_planes, P
     }
     {
         StageTimer t(c, st, HHGT_STAGE_LZ4);
+        if (!w.lz_flags.p) {
+            TRY(w.lz_flags.ensure(8));
+            HIP_TRY(hipMemsetAsync(w.lz_flags.p, 0, 8, st));
+        }
+        if (++w.lz_tag == 0) w.lz_tag = 1;
         TRY(launch_lz4_blocks(static_cast<const uint8_t *>(d_src), static_cast<const uint8_t *>(d_planes), pg, n_chunks, chunk_nbytes, typesize,
-                              blocksize, w.lz_scratch.as<uint8_t>(), slot, w.lz_csize.as<uint32_t>(), c->clevel, st));
+                              blocksize, w.lz_scratch.as<uint8_t>(), slot, w.lz_csize.as<uint32_t>(), c->clevel, w.lz_flags.as<uint32_t>(),
+                              w.lz_tag, st));
         t.stop();
     }
     if (fst != st) {

@@ -162,7 +162,8 @@ struct hhgt_ctx {
     // two sets: with a frame stream (hhgt_set_frame_stream) the framing of call k reads set k & 1 while the LZ4 kernels of
     // call k + 1 write the other
     struct CodecWs {
-        DevBuf lz_scratch, lz_csize, fr_bsize, fr_csize, fr_flags, fr_state;
+        DevBuf lz_scratch, lz_csize, lz_flags, fr_bsize, fr_csize, fr_flags, fr_state;
+        uint32_t lz_tag = 0;       // tag of the last launch_lz4_blocks on lz_flags
         uint32_t fr_tag = 0;       // launch tag of k_frame_fused's state words (1 .. 2^20 - 1, then the buffer is zeroed again)
         hipEvent_t lz_done = nullptr, fr_done = nullptr;
         bool fr_pending = false;   // fr_done was recorded behind a framing that read this set
@@ -255,10 +256,13 @@ size_t lz4_slot_bytes(int neblock);
 // d_planes != NULL: the chunks exist as bit planes (hhgt.h "Bit-plane form"); d_src then only supplies the bytes of calls
 // beyond 0 / 1 / missing and may be NULL
 int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel, hipStream_t st);
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel, uint32_t *d_flags, uint32_t tag,
+                      hipStream_t st);
+// d_flags (two words, zero once; may be NULL) + tag (a value no earlier call on these words used, not 0): the coders note in
+// them whether they left streams marked, and the scanning launches behind return at once when nobody did
 // lz4bits.hip: typesize 2, 8 KiB blocks; streams it cannot code get csize = 0xFFFFFFFF
 int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
-                         int depth, hipStream_t st);
+                         int depth, uint32_t *d_flags, uint32_t tag, bool *exc_ran, hipStream_t st);
 // frame.hip
 int launch_frame(const uint8_t *d_scratch, size_t slot_bytes, const uint32_t *d_csize, const uint8_t *d_src, const uint8_t *d_planes,
                  PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize, int blocksize, int format,

@@ -659,10 +659,12 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
                                                      uint32_t split, uint32_t sstride, uint32_t hashlog, uint32_t algo,
                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
                                                      uint32_t *__restrict__ csize, uint32_t n_total, const uint8_t *__restrict__ planes,
-                                                     PlanesGeom pg)
+                                                     PlanesGeom pg, const uint32_t *__restrict__ mark_flag, uint32_t tag)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nwaves = blockDim.x >> 6;
+    // scan mode: the bit-plane coders say whether they left anything (lz4bits.hip: the word holds this call's tag if so)
+    if (mark_flag && __builtin_nontemporal_load(mark_flag) != tag) return;
     // algo bit 8: scan mode — only the streams the bit-plane encoders (lz4bits.hip) left marked (csize == 0xFFFFFFFF) are
     // coded: the (small, fixed) grid scans the stream sizes, 64 blocks per load, and works on the blocks that still hold one
     const bool only_marked = (algo & 0x100u) != 0u;
@@ -783,8 +785,10 @@ __global__ __launch_bounds__(MW ? 128 : 1024, MW ? MW : 1) void k_lz4_blocks(con
 }
 
 int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom pg, uint64_t n_chunks, uint64_t chunk_nbytes, int typesize,
-                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel, hipStream_t st)
+                      int blocksize, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize, int clevel, uint32_t *d_flags, uint32_t tag,
+                      hipStream_t st)
 {
+    const uint32_t *mark_flag = nullptr;   // scan mode: where the last bit-plane coder of this call says whether it left marks
     if (d_planes && (typesize != 2 || blocksize != 8192 || chunk_nbytes % 8192 || (reinterpret_cast<uintptr_t>(d_planes) & 15u))) {
         hhgt_set_error("lz4: bit planes stand for typesize 2, 8 KiB blocks, chunks of whole blocks, 16-byte aligned");
         return HHGT_ERR_ARG;
@@ -804,9 +808,11 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
         static const int lazy_env = getenv("HHGT_LZ4_LAZY") ? atoi(getenv("HHGT_LZ4_LAZY")) : -1;
         int depth = depth_env >= 0 ? depth_env : (clevel <= 2 ? 0 : clevel <= 4 ? 1 : clevel <= 6 ? 2 : clevel == 7 ? 4 : clevel == 8 ? 8 : 12);
         if ((lazy_env < 0 ? clevel >= 9 && depth == 12 : lazy_env != 0) && (depth == 2 || depth == 12)) depth |= 0x100;
+        bool exc_ran = false;
         const int rc = launch_lz4_bitplanes(d_planes ? d_planes : d_src, d_planes != nullptr, pg, n_chunks * (chunk_nbytes / 8192), d_scratch,
-                                            slot_bytes, d_csize, depth, st);
+                                            slot_bytes, d_csize, depth, d_flags, tag, &exc_ran, st);
         if (rc != HHGT_OK) return rc;
+        if (d_flags) mark_flag = d_flags + (exc_ran ? 1 : 0);
     }
     const uint32_t split = (typesize >= 2 && typesize <= 16 && blocksize / typesize >= 128) ? 1u : 0u;
     const uint32_t nwaves = split ? (uint32_t)typesize : 1u;
@@ -879,7 +885,7 @@ int launch_lz4_blocks(const uint8_t *d_src, const uint8_t *d_planes, PlanesGeom 
 #define LZ_LAUNCH2(MWV, ALG, PL)                                                                                      \
     hipLaunchKernelGGL((k_lz4_blocks<MWV, ALG, PL>), dim3((uint32_t)grid), dim3(64u * nwaves), lds, st, d_src, nblocks, \
                        chunk_nbytes, (uint32_t)typesize, (uint32_t)blocksize, split, sstride, hashlog, algo, d_scratch, \
-                       (uint64_t)slot_bytes, d_csize, (uint32_t)(n_chunks * nblocks), d_planes, pg)
+                       (uint64_t)slot_bytes, d_csize, (uint32_t)(n_chunks * nblocks), d_planes, pg, mark_flag, tag)
 #define LZ_LAUNCH(MWV, ALG) LZ_LAUNCH2(MWV, ALG, false)
     // effort: 1 = run candidate only (clevel 1-2), 0 = hash + run candidates (clevel 3-6, the default 5), 2 = plus the
     // long-run source candidate (clevel 7-9)

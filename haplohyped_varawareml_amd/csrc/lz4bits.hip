@@ -53,8 +53,24 @@
 #ifndef BP_WAVES
 #define BP_WAVES 7       // waves per SIMD the plain instantiations are compiled for (LDS must allow 2 x BP_WAVES workgroups per CU)
 #endif
-#define BP_PTRASH (BP_MAXONES + 7)   // P's spare entry: written by lanes that have nothing to store, never read
 #define BP_QCAP 100     // queued coded ones a wave can hold (a window adds at most 64 to fewer than 64)
+// the exception-aware instantiation carries a second bit map and the ones' classes (624 bytes per wave): its list and its staging
+// area are smaller by as much, so that it too stays under 11 KiB per workgroup = 14 workgroups per CU, 7 waves per SIMD (round 4;
+// it ran at 13 / 6 before, and this kernel's time is 1 / occupancy)
+#ifndef BP_MAXONES_EXC
+#define BP_MAXONES_EXC 540
+#endif
+#ifndef BP_STAGE_EXC
+#define BP_STAGE_EXC 448
+#endif
+#ifndef BP_WAVES_EXC
+#define BP_WAVES_EXC 7
+#endif
+template <bool EXC> struct BpCfg {
+    static constexpr uint32_t MAXONES = EXC ? BP_MAXONES_EXC : BP_MAXONES;
+    static constexpr uint32_t STAGE = EXC ? BP_STAGE_EXC : BP_STAGE;
+    static constexpr uint32_t PTRASH = MAXONES + 7;   // P's spare entry: written by lanes that have nothing to store, never read
+};
 #define BP_HLOG 6
 #define BP_GAPCLIP 40
 #define BP_MINM 6     // total length a hash match must have
@@ -78,11 +94,11 @@ template <bool CHAIN, bool EXC> struct BpLds {
     uint32_t tab[1 << BP_HLOG];      // min(gap behind the one + 1, BP_GAPCLIP) -> one index + 1
     uint8_t flag[72];                // pointer-doubling marks of a window ([0, 64]; [68]: where lanes with nothing to mark write)
     uint16_t wpre[64];               // ones in front of bit-map word w (64-bit words)
-    uint16_t P[BP_MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
-    uint16_t chain[CHAIN ? BP_MAXONES + 8 : 4];   // chain[j + 1] = (previous one with the same context hash) + 1, 0 = none
-    uint32_t gbw[(BP_MAXONES + 16) / 4];   // gap bytes: zeros behind the one with P-index i, clipped to 255 (255 from the last one on)
+    uint16_t P[BpCfg<EXC>::MAXONES + 8];      // P[j + 1] = q_j + 1 (P[0] = 0: a virtual one at -1; P[m + 1] = P[m + 2] = n + 1)
+    uint16_t chain[CHAIN ? BpCfg<EXC>::MAXONES + 8 : 4];   // chain[j + 1] = (previous one with the same context hash) + 1, 0 = none
+    uint32_t gbw[(BpCfg<EXC>::MAXONES + 16) / 4];   // gap bytes: zeros behind the one with P-index i, clipped to 255 (255 from the last one on)
     uint2 queue[BP_QCAP + 1];        // coded ones waiting for layout + emission (bp_emit_batch takes 64 at a time); [BP_QCAP]: written by lanes that queue nothing
-    uint8_t stage[BP_STAGE + 8];     // output staged here, written out in coalesced dwords; [BP_STAGE]: written by lanes that have no byte to store
+    uint8_t stage[BpCfg<EXC>::STAGE + 8];     // output staged here, written out in coalesced dwords; [BP_STAGE]: written by lanes that have no byte to store
 };
 
 // a queued coded one: what its sequences need that does not depend on the sequences in front of it
@@ -294,19 +310,19 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
     BP_MARK("sizes_done");
     // the batch's bytes go to the staging area; what is staged leaves in coalesced dwords when the next batch would not
     // fit (a batch larger than the whole area is written to global memory directly)
-    if (__builtin_expect(sop + total > BP_STAGE, 0)) {
+    if (__builtin_expect(sop + total > BpCfg<EXC>::STAGE, 0)) {
         bp_flush(S.stage, out + gop, sop, lane);
         gop += sop;
         sop = 0;
     }
     const uint32_t at = sincl - (szM + szT);
-    if (__builtin_expect(total > BP_STAGE, 0)) {   // (wave-uniform, rare: a batch with hundreds of literals)
+    if (__builtin_expect(total > BpCfg<EXC>::STAGE, 0)) {   // (wave-uniform, rare: a batch with hundreds of literals)
         bp_put_seq<EXC, false>(bm, xm, out + gop, 0u, at, pe, ms, lenM, off, onM, lane);
         bp_put_seq<EXC, false>(bm, xm, out + gop, 0u, at + szM, pe2, rs, lenT, 1u, onT, lane);
         gop += total;
     } else {
-        bp_put_seq<EXC, true>(bm, xm, S.stage + sop, BP_STAGE - sop, at, pe, ms, lenM, off, onM, lane);
-        bp_put_seq<EXC, true>(bm, xm, S.stage + sop, BP_STAGE - sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
+        bp_put_seq<EXC, true>(bm, xm, S.stage + sop, BpCfg<EXC>::STAGE - sop, at, pe, ms, lenM, off, onM, lane);
+        bp_put_seq<EXC, true>(bm, xm, S.stage + sop, BpCfg<EXC>::STAGE - sop, at + szM, pe2, rs, lenT, 1u, onT, lane);
         sop += total;
     }
     prev_end = (uint32_t)__builtin_amdgcn_readlane((int)F, (int)(n - 1u));
@@ -328,10 +344,16 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
 // carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
 // Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
 template <int DEPTH, bool PLANES, bool EXC, bool LAZY = false>
-__global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
-                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize)
+__global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
+                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
+                                                          uint32_t *__restrict__ flags, uint32_t tag)
 {
     static_assert(!EXC || PLANES, "the exception-aware coder reads bit planes");
+    // flags (may be null): flags[0] == tag <=> the plain instantiation of THIS call left a stream marked, flags[1] == tag <=> the
+    // exception-aware one did.  The scanning launches behind (this kernel with EXC, lz4.hip's kernel in scan mode) look at the
+    // word first and are gone if nobody marked anything — on the headline cohort that is every call, and the two scans were
+    // 48 us of each shard's chain (r04b_bench_kernel_stats.csv).  A tag per call instead of a flag somebody has to clear.
+    if (EXC && flags && __builtin_nontemporal_load(flags) != tag) return;
     constexpr bool CHAIN = DEPTH > 1;
     __shared__ BpLds<CHAIN, EXC> lds[2];
     __shared__ uint32_t nonbin[2][2];
@@ -455,7 +477,9 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
     const uint32_t cnt = (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
     const uint32_t incl = bp_scan_sum(cnt, lane);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (nonbinary || m > BP_MAXONES) {
+    if (nonbinary || m > BpCfg<EXC>::MAXONES) {
+        // (the flag: read first — the line sits in the L2 and after the first few marking waves of an XCD it holds the tag)
+        if (lane == 0 && flags && flags[EXC ? 1 : 0] != tag) flags[EXC ? 1 : 0] = tag;
         if (EXC) BP_DONE();   // stays marked: the byte-wise kernel scans for it next
         if (lane == 0) csize[sidx] = 0xFFFFFFFFu;   // left to the next coder
         return;
@@ -470,13 +494,13 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
         // (no `if (lo != 0)` around the body: a lane that has run out stores to P's spare entry — an exec-mask region costs
         // two scalar instructions and a branch per round, and scalar issue is this kernel's tightest port)
         uint32_t lo = wlo, hi = whi, at = incl - cnt + 1u;
-        P[lane == 0u ? 0u : BP_PTRASH] = 0;
+        P[lane == 0u ? 0u : BpCfg<EXC>::PTRASH] = 0;
         uint32_t base = 64u * lane + 1u;
         while (__builtin_amdgcn_ballot_w64(lo != 0u) != 0ull) {
             const bool on = lo != 0u;
             const uint32_t bpos = (uint32_t)__builtin_ctz(lo | 0x80000000u);
             if (EXC && on && ((xlo >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));   // (LDS: ds_or_b32)
-            P[on ? at : BP_PTRASH] = (uint16_t)(base + bpos);
+            P[on ? at : BpCfg<EXC>::PTRASH] = (uint16_t)(base + bpos);
             at += on ? 1u : 0u;
             lo &= lo - 1u;
         }
@@ -485,17 +509,17 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
             const bool on = hi != 0u;
             const uint32_t bpos = (uint32_t)__builtin_ctz(hi | 0x80000000u);
             if (EXC && on && ((xhi >> bpos) & 1u)) atomicOr(&S.cls[at >> 5], 1u << (at & 31u));
-            P[on ? at : BP_PTRASH] = (uint16_t)(base + bpos);
+            P[on ? at : BpCfg<EXC>::PTRASH] = (uint16_t)(base + bpos);
             at += on ? 1u : 0u;
             hi &= hi - 1u;
         }
-        P[lane < 4u ? m + 1u + lane : BP_PTRASH] = (uint16_t)(BP_N + 1);
+        P[lane < 4u ? m + 1u + lane : BpCfg<EXC>::PTRASH] = (uint16_t)(BP_N + 1);
     }
     BP_FENCE();
     if (DEPTH > 0) {   // gap bytes of all ones (a candidate is compared on them, 4 at a time)
         uint8_t *gb = reinterpret_cast<uint8_t *>(S.gbw);
         for (uint32_t i = lane; i < m + 8u; i += 64u) {
-            const uint32_t i1 = i + 1u < BP_PTRASH ? i + 1u : BP_PTRASH;   // (i < m + 8 <= 644: the loads stay inside P)
+            const uint32_t i1 = i + 1u < BpCfg<EXC>::PTRASH ? i + 1u : BpCfg<EXC>::PTRASH;   // (i < m + 8 <= 644: the loads stay inside P)
             uint32_t g = (uint32_t)P[i1] - (uint32_t)P[i1 - 1u] - 1u;
             g = g < 255u ? g : 255u;
             gb[i] = (uint8_t)(i < m ? g : 255u);
@@ -788,12 +812,12 @@ __global__ __launch_bounds__(128, EXC ? 6 : BP_WAVES) void k_lz4_bitplanes(const
     {
         const uint32_t ll = BP_N - prev_end, llx = bp_len_ext(ll);
         BP_FENCE();
-        if (sop + 1u + llx + ll > BP_STAGE) {
+        if (sop + 1u + llx + ll > BpCfg<EXC>::STAGE) {
             bp_flush(S.stage, out + gop, sop, lane);
             gop += sop;
             sop = 0;
         }
-        const bool direct = 1u + llx + ll > BP_STAGE;
+        const bool direct = 1u + llx + ll > BpCfg<EXC>::STAGE;
         auto tail = [&](auto dstp) {
             if (lane == 0) {
                 dstp[0] = (uint8_t)((ll < 15u ? ll : 15u) << 4);
@@ -846,8 +870,9 @@ bp_next:;
 
 // depth: candidates per one; + 0x100: with the lazy rule (instantiated for 12 candidates — clevel 9 — and, for measurements, 2)
 int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint64_t n_blocks, uint8_t *d_scratch, size_t slot_bytes, uint32_t *d_csize,
-                         int depth, hipStream_t st)
+                         int depth, uint32_t *d_flags, uint32_t tag, bool *exc_ran, hipStream_t st)
 {
+    if (exc_ran) *exc_ran = false;
     const bool lazy = (depth & 0x100) != 0;
     depth &= 0xFF;
     if (n_blocks == 0) return HHGT_OK;
@@ -861,17 +886,19 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint6
     // the exception-aware instantiation scans for the streams the plain one marked, on a grid that fills the chip
     // (HHGT_LZ4_EXC=0: every marked stream goes to the byte-wise kernel, as before round 3)
     static const bool exc_env = !(getenv("HHGT_LZ4_EXC") && atoi(getenv("HHGT_LZ4_EXC")) == 0);
-    const uint32_t exc_grid = (uint32_t)((n_blocks + 63) / 64 < 256u * 12u ? (n_blocks + 63) / 64 : 256u * 12u);
+    const uint32_t exc_grid = (uint32_t)((n_blocks + 63) / 64 < 256u * 14u ? (n_blocks + 63) / 64 : 256u * 14u);
 #define BP_LAUNCH2(D, PL, LZ)                                                                                               \
     hipLaunchKernelGGL((k_lz4_bitplanes<D, PL, false, LZ>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
-                       d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize)
+                       d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize, d_flags, tag)
 #define BP_LAUNCH(D, LZ)                                                                                                    \
     do {                                                                                                                    \
         if (planes) {                                                                                                       \
             BP_LAUNCH2(D, true, LZ);                                                                                        \
-            if (exc_env)                                                                                                    \
+            if (exc_env) {                                                                                                  \
                 hipLaunchKernelGGL((k_lz4_bitplanes<D, true, true, LZ>), dim3(exc_grid), dim3(128), 0, st, d_src, pg, (uint32_t)n_blocks, d_scratch, \
-                                   (uint64_t)slot_bytes, d_csize);                                                          \
+                                   (uint64_t)slot_bytes, d_csize, d_flags, tag);                                            \
+                if (exc_ran) *exc_ran = true;                                                                               \
+            }                                                                                                               \
         } else                                                                                                              \
             BP_LAUNCH2(D, false, LZ);                                                                                       \
     } while (0)

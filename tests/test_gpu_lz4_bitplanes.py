@@ -234,7 +234,7 @@ def with_missing(rng, planes, frac):
     return out
 
 
-@pytest.mark.parametrize("scale,frac,seed", [(1.0, 0.025, 11), (1.0, 0.002, 12), (0.25, 0.025, 13), (1.0, 0.0, 14), (2.0, 0.05, 15)])
+@pytest.mark.parametrize("scale,frac,seed", [(1.0, 0.025, 11), (1.0, 0.002, 12), (0.25, 0.025, 13), (1.0, 0.0, 14), (1.5, 0.03, 15), (2.0, 0.05, 16)])
 def test_planes_with_missing_calls_match_the_reference(ctx, ref, scale, frac, seed):
     rng = np.random.default_rng(seed)
     planes = with_missing(rng, bench_like(rng, 128, scale), frac)
@@ -248,7 +248,8 @@ def test_planes_with_missing_calls_match_the_reference(ctx, ref, scale, frac, se
         n_ref += 1
         n_exc += bool((pl == 0xF7).any())
         assert np.array_equal(got[k], want), f"plane {k}: stream differs from gapenc_ref ({got[k].size} vs {want.size} bytes)"
-    assert n_ref >= (100 if scale <= 1 else 40)
+    # (planes with missing calls and more than 540 nonzero bytes are left to the byte-wise encoder: at scale 2 that is all of them)
+    assert n_ref >= (100 if scale <= 1 else 40 if scale < 2 else 0)
     if frac >= 0.002:
         assert n_exc >= n_ref // 2               # most planes really went through the exception-aware instantiation
 

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #define N_MAXONES 636
+#define N_MAXONES_EXC 540   /* planes with a missing call: the exception-aware instantiation's list is shorter (csrc/lz4bits.hip BP_MAXONES_EXC) */
 #define HLOG 6
 #define GAPCLIP 40
 #define MINM 6
@@ -69,7 +70,7 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
     static __thread int chain[4100];
     static __thread int P[4096 + 4];
     static __thread uint8_t cls[4096 + 32];
-    int m = 0;
+    int m = 0, has_exc = 0;
     P[0] = 0;
     memset(cls, 0, sizeof(cls));
     for (int i = 0; i < n; ++i) {
@@ -77,9 +78,11 @@ int gapenc_ref(const uint8_t *in, int n, uint8_t *out, int depth)
         if (in[i]) {
             if (m >= N_MAXONES) return -1;
             cls[1 + m] = in[i] == 0xF7;
+            has_exc |= in[i] == 0xF7;
             P[1 + m++] = i + 1;
         }
     }
+    if (has_exc && m > N_MAXONES_EXC) return -1;
     P[m + 1] = P[m + 2] = n + 1;
     // gap bytes: GB[i] = zeros behind the one with P-index i (i = 0: the virtual one in front), clipped to 255; the last
     // real one and everything behind it read 255 = "agrees with nothing"
