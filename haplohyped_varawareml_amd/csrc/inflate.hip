@@ -124,7 +124,11 @@ __device__ __forceinline__ uint32_t clc_order(uint32_t i)
 }  // namespace
 
 // grid = ceil(n_members / 4); block = 256 (wave w of a block inflates member 4 * blockIdx + w; no barriers)
-__global__ __launch_bounds__(256) void k_inflate_members(const uint8_t *__restrict__ src, uint64_t src_bytes,
+#ifndef INF_WGS
+#define INF_WGS 7   // workgroups per CU the kernel is compiled for: 72 registers + 36 bytes of scratch per lane, seven waves per SIMD —
+                    // 210 against 198 GB/s of text at 18 k members (6: 74 registers, no scratch; 8: slower, round 3)
+#endif
+__global__ __launch_bounds__(256, INF_WGS) void k_inflate_members(const uint8_t *__restrict__ src, uint64_t src_bytes,
                                                          const unsigned long long *__restrict__ comp_off,
                                                          const uint32_t *__restrict__ comp_len,
                                                          const unsigned long long *__restrict__ out_off,
