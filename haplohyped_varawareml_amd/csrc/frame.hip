@@ -128,6 +128,8 @@ __device__ __forceinline__ void wave_copy_load(WaveCopy &c, const uint8_t *__res
 {
     const uint32_t o = (threadIdx.x & 63u) * 16u;
     c.a = u32x4_fr{0u, 0u, 0u, 0u};
+    // (loading the slot's first KiB whatever n is — the load then waits for no size, one round trip less per wave — was
+    // measured: 1.94 against 1.74 ms per step; the kernel is bound by what it moves, not by its chain)
     if (o < n) c.a = *reinterpret_cast<const u32x4_fr *>(src + o);   // (a slot is padded to 16 bytes: the last piece may read past n)
 }
 
