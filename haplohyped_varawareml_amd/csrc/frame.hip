@@ -242,6 +242,9 @@ __device__ __forceinline__ void frame_block(const FrameParams &P, const uint8_t 
     if (ns == 2u) {  // the genotype case (typesize 2): both planes' loads in flight before the first store
         const uint32_t cs0 = (uint32_t)__builtin_amdgcn_readlane((int)cs_l, 0), cs1 = (uint32_t)__builtin_amdgcn_readlane((int)cs_l, 1);
         uint8_t *d0 = cdst + q + 4u, *d1 = d0 + cs0 + 4u;
+        // (the stores below start at any byte; a timing-only build that rounded d0 / d1 down to 16 bytes ran the stage in the
+        // same 1.73-1.75 ms: the alignment of the stores is not what the kernel waits for, so a destination-driven gather
+        // with aligned stores was not built)
         const uint8_t *s0 = scratch + sidx0 * P.slot_bytes, *s1 = s0 + P.slot_bytes;
         WaveCopy c0, c1;
         wave_copy_load(c0, d0, s0, cs0);
