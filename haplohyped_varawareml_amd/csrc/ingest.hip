@@ -508,7 +508,9 @@ bool run_reader_input(hhgt_ingest *g, Input *in)
             break;
         }
         TextBuf &tb = g->text[(size_t)ti];
-        if (hipMemcpyAsync(tb.d, ptr, n, hipMemcpyHostToDevice, g->s_copy) != hipSuccess ||
+        // (a device-inflated input before this one may still have a carry copy out of this buffer queued on its own stream)
+        if ((g->last_carry && hipStreamWaitEvent(g->s_copy, g->last_carry, 0) != hipSuccess) ||
+            hipMemcpyAsync(tb.d, ptr, n, hipMemcpyHostToDevice, g->s_copy) != hipSuccess ||
             hipEventRecord(tb.ready, g->s_copy) != hipSuccess || hipEventRecord(cev[k & 1], g->s_copy) != hipSuccess) {
             fail(g, HHGT_ERR_HIP, "ingest: upload of a text block failed");
             ok = false;
@@ -574,6 +576,7 @@ bool run_memory_input(hhgt_ingest *g, Input *in)
         int ti;
         if (!take_text(g, &ti, (size_t)n + 64)) return false;
         TextBuf &tb = g->text[(size_t)ti];
+        if (g->last_carry) G_HIP(hipStreamWaitEvent(g->s_copy, g->last_carry, 0));   // (see run_reader_input)
         G_HIP(hipMemcpyAsync(tb.d, p + pos, n, hipMemcpyHostToDevice, g->s_copy));
         G_HIP(hipEventRecord(tb.ready, g->s_copy));
         tb.nbytes = n;
