@@ -278,3 +278,30 @@ def test_gzip_stream_that_ends_on_a_block_boundary(ctx, tmp_path):
     r = run_engine(ctx, [(p, "chr6")], sc=64, vc=512, fmt=dev.BLOSC1, block_bytes=1 << 20, n_threads=2)[0]
     check_against_oracle(r, text, S, "chr6", 64, 512)
     assert r["stats"]["n_kept"] == n_rec and n_rec % 512 != 0     # the last column was open when the stream ended
+
+
+def test_device_and_host_inputs_alternate_in_one_engine(ctx, tmp_path):
+    """device-inflated BGZF files (many blocks: two inflate streams, the line carry on a third), a plain file, pinned memory
+    and a gzip stream, in turn through ONE engine with the `auto` policy: every input's matrix, tables and chunks against
+    the oracle — the text buffers and staging slots go round between the two kinds of source"""
+    S, sc, vc = 200, 64, 512
+    jobs, texts = [], []
+    for k, kind in enumerate(["bgzf", "plain", "bgzf", "memory", "gzip", "bgzf"]):
+        V = 7000 + 900 * k
+        tab = synth.variant_table(30 + k, V, S)
+        text, _ = synth.render_fixed_numpy(f"chr{k + 1}", tab, S, seed=30 + k)
+        p = str(tmp_path / f"in{k}.vcf{'' if kind == 'plain' else '.gz'}")
+        if kind == "bgzf":
+            write_bgzf(p, text, level=6)
+        elif kind == "gzip":
+            with gzip.open(p, "wb", compresslevel=1) as f:
+                f.write(text)
+        elif kind == "plain":
+            open(p, "wb").write(text)
+        jobs.append((torch.frombuffer(bytearray(text), dtype=torch.uint8).pin_memory() if kind == "memory" else p, f"chr{k + 1}"))
+        texts.append(text)
+    res = run_engine(ctx, jobs, sc=sc, vc=vc, fmt=dev.BLOSC1, device_inflate="auto", block_bytes=5 << 20, n_threads=3)
+    for k, text in enumerate(texts):
+        check_against_oracle(res[k], text, S, f"chr{k + 1}", sc, vc, runs=[(0, f"chr{k + 1}")])
+    dev_inputs = [k for k in res if res[k]["stats"]["device_inflate"]]
+    assert dev_inputs == [0, 2, 5] and all(res[k]["stats"]["n_blocks"] >= 2 for k in dev_inputs)
