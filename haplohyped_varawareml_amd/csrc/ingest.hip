@@ -1401,8 +1401,11 @@ extern "C" int hhgt_ingest_open(hhgt_ctx *ctx, const hhgt_ingest_opts *opts, hhg
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hip(hipStreamCreateWithPriority(&g->s_copy, hipStreamNonBlocking, prio_hi), "stream");
-    hip(hipStreamCreateWithFlags(&g->s_inf, hipStreamNonBlocking), "stream");
-    hip(hipStreamCreateWithFlags(&g->s_inf2, hipStreamNonBlocking), "stream");
+    // the inflate streams at the lowest priority (HHGT_INGEST_INF_PRIO=0: the default one): one wave per member lives for the
+    // whole launch, so a freed wave slot should go to the encode / compress kernels of the block before, not to the next inflate
+    static const bool inf_low = !(getenv("HHGT_INGEST_INF_PRIO") && atoi(getenv("HHGT_INGEST_INF_PRIO")) == 0);
+    hip(hipStreamCreateWithPriority(&g->s_inf, hipStreamNonBlocking, inf_low ? prio_lo : 0), "stream");
+    hip(hipStreamCreateWithPriority(&g->s_inf2, hipStreamNonBlocking, inf_low ? prio_lo : 0), "stream");
     hip(hipStreamCreateWithFlags(&g->s_carry, hipStreamNonBlocking), "stream");
     hip(hipStreamCreateWithPriority(&g->s_out, hipStreamNonBlocking, prio_hi), "stream");
     const bool dev = g->o.device_inflate != 0;
