@@ -430,6 +430,16 @@ def ingest_legs(ctx, shards, S, e2e_chroms, fed_chroms, fmt, dist, world, reduce
             return 3 * h0.numel() / (time.perf_counter() - t) / 1e9
 
         link = h2d_rate()
+        # The files above took tens of seconds of host work with the GPU idle, and a GPU that has idled takes tens of milliseconds
+        # to clock up again — inside the first pass of the first leg otherwise (host_fed: 0.22 against 0.17 s, where the same leg
+        # in tools/e2e_bench.py, whose preparation keeps the GPU busy, has first pass = steady pass).  ~0.1 s of device work first:
+        # the legs' `first_pass` is then what a cold ENGINE costs, not a cold clock.
+        if fed:
+            wu = torch.empty(256 << 20, dtype=torch.uint8, device=ctx.device)
+            for _ in range(40):
+                wu.add_(1)
+            torch.cuda.synchronize()
+            del wu
         n_threads = host["n_threads"] if world > 1 else 0      # N ranks: each its share of the granted CPUs
 
         def run(jobs, device_inflate, want_v, passes=2):
