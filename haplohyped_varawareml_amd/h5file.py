@@ -17,6 +17,7 @@ repository pins bit-exactly against c-blosc 1.21 (oracle/codec_oracle.c, tests/t
 Verified in tests/test_h5file.py with the image's independent libhdf5 1.10.6 (h5py 3.3 under /opt/conda,
 when present): structure, dtypes, shapes, chunk index and raw chunk bytes (`read_direct_chunk`).
 """
+import os
 import struct
 
 import numpy as np
@@ -70,21 +71,44 @@ class H5Writer:
     """Append-only writer.  Usage:
         w = H5Writer(path); addr = w.append(chunk_bytes) ...; w.add_chunked(...); w.add_array(...); w.close()"""
 
+    PAR_MIN = 8 << 20      # appends at least this large are written by PAR_THREADS threads (os.pwrite releases the GIL:
+    PAR_THREADS = int(os.environ.get("HHGT_H5_WRITE_THREADS", "8"))   # one thread copies ~2 GB/s into the page cache, and the converter appends 40 MB batches)
+
     def __init__(self, path):
-        self.f = open(path, "wb")
-        self.f.write(b"\0" * 2048)            # superblock goes here at close
+        self.f = open(path, "wb", buffering=0)   # unbuffered: every write is a pwrite at an address this object keeps
+        self.fd = self.f.fileno()
+        os.pwrite(self.fd, b"\0" * 2048, 0)    # superblock goes here at close
         self.pos = 2048
         self.groups = {"/": {}}              # group path -> {name: ("group", path) | ("dataset", header_addr)}
+        self._pool = None
 
     # ---- raw space ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _pwrite_all(fd, mv, pos):
+        while len(mv):
+            k = os.pwrite(fd, mv, pos)
+            mv = mv[k:]
+            pos += k
+
     def append(self, data, align=8):
         pad = -self.pos % align
         if pad:
-            self.f.write(b"\0" * pad)
+            os.pwrite(self.fd, b"\0" * pad, self.pos)
             self.pos += pad
         addr = self.pos
-        self.f.write(memoryview(data))
-        self.pos += len(data)
+        mv = memoryview(data).cast("B")
+        n = len(mv)
+        if n >= self.PAR_MIN:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self.PAR_THREADS)
+            step = -(-n // self.PAR_THREADS)
+            step = -(-step // 4096) * 4096
+            for fut in [self._pool.submit(self._pwrite_all, self.fd, mv[o:o + step], addr + o) for o in range(0, n, step)]:
+                fut.result()
+        else:
+            self._pwrite_all(self.fd, mv, addr)
+        self.pos += n
         return addr
 
     # ---- tree of names -----------------------------------------------------------------------------------------
@@ -175,7 +199,7 @@ class H5Writer:
                                              addrs[gi + 1] if gi + 1 < len(groups) else UNDEF) + body
                 out += node + b"\0" * (node_bytes - len(node))
                 nxt.append((g[0][0], g[0][1], addrs[gi]))
-            self.f.write(out)
+            self._pwrite_all(self.fd, memoryview(bytes(out)), self.pos)
             self.pos += len(out)
             if len(groups) == 1:
                 return addrs[0]
@@ -222,8 +246,10 @@ class H5Writer:
         eof = self.pos
         sb = SIG + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0) + struct.pack("<HHI", LEAF_K, GROUP_K, 0) + \
             struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF) + struct.pack("<QQI4xQQ", 0, hdr, 1, bt, hp)
-        self.f.seek(0)
-        self.f.write(sb)
+        os.pwrite(self.fd, sb, 0)
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
         self.f.close()
         self.f = None
 

@@ -210,6 +210,94 @@ class GenotypeStore:
 DONOR_CHUNK_ROWS = 7488          # 8 Blosc blocks of 936 records (32 760 B = the largest multiple of 35 under 32 KiB)
 
 
+def _h5_strings(xs):
+    n = max([len(x.encode()) for x in xs] + [1])
+    return np.array([x.encode() for x in xs], dtype=f"S{n}")
+
+
+def _h5_group_datasets(w, group, meta, g, base, off, start, ref, alt, runs):
+    """the datasets of group chr_{N} (see export_h5): the chunk index of /genotype over chunk bytes already in the file at
+    base + off[k], and the variant tables"""
+    from .h5file import FILTER_BLOSC, blosc_cd_values
+    sc, vc, S = meta["sc"], meta["vc"], len(meta["samples"])
+    off = np.asarray(off, np.uint64)
+    ids = np.arange(len(off) - 1)
+    vcol, scol = ids // max(g["n_scol"], 1), ids % max(g["n_scol"], 1)
+    chunks = [((int(sci) * sc, int(vci) * vc, 0), base + int(o0), int(o1 - o0))
+              for sci, vci, o0, o1 in zip(scol, vcol, off[:-1], off[1:])]
+    w.add_chunked(group, "genotype", (S, g["n_variants"], 2), np.int8, (sc, vc, 2), chunks, filter_id=FILTER_BLOSC,
+                  cd_values=blosc_cd_values(meta["typesize"], sc * vc * 2), filter_name=b"blosc")
+    start = np.asarray(start)
+    w.add_array(group, "start", start.astype(np.uint32))
+    w.add_array(group, "stop", (start + 1).astype(np.uint32))
+    w.add_array(group, "ref", np.asarray(ref).astype(np.uint8).view("S1"))
+    w.add_array(group, "alt", np.asarray(alt).astype(np.uint8).view("S1"))
+    w.add_array(group, "chrom_run_first", np.array([r[0] for r in runs], np.uint32))
+    w.add_array(group, "chrom_run_name", _h5_strings([r[1] for r in runs]) if runs else np.zeros(0, "S1"))
+
+
+class H5CohortWriter:
+    """StoreWriter's interface (begin_group / add_chunks / add_variants / add_chrom_runs / end_group / close, .meta) writing
+    straight into OUT/{cohort}.h5: the chunk bytes of a group are appended to the file as the engine hands them over, its
+    chunk index and tables follow at end_group — the file export_h5 makes from a store, without the store and without the
+    second copy of every chunk (round 4: the converter's 3 M x 2504 run was 1.1 s of engine + store and 1.1 s of export).
+    Used by the converter when one GPU does the work and neither the store nor the per-donor datasets are asked for."""
+
+    def __init__(self, h5_path, samples, sc, vc, typesize=2, cohort_name="", donor_ids=None):
+        from .h5file import H5Writer
+        self.path = h5_path
+        self.meta = dict(format="hhgt-store", version=1, cohort_name=cohort_name, samples=list(samples),
+                         donor_ids=list(donor_ids) if donor_ids is not None else list(samples),
+                         sc=int(sc), vc=int(vc), typesize=int(typesize), blocksize=min(int(vc) * 2, 8192),
+                         chunk_format="blosc1", codec="blosc1: byte-shuffle + LZ4 block format", groups={})
+        self.w = H5Writer(h5_path)
+        self._cur = None
+        self._named = False
+
+    def _names(self):
+        # /samples and /donor_ids first, as export_h5 writes them (the sample names arrive with the first header, before the
+        # first group begins): the file comes out byte-identical to the one exported from a store
+        if not self._named:
+            self.w.add_array("/", "samples", _h5_strings(self.meta["samples"]))
+            self.w.add_array("/", "donor_ids", _h5_strings(self.meta["donor_ids"]))
+            self._named = True
+
+    def begin_group(self, group):
+        self._names()
+        self._cur = dict(name=group, base=None, offsets=[0], start=[], ref=[], alt=[], runs=[], n_variants=0, raw_bytes=0)
+
+    def add_chunks(self, data, offsets, raw_bytes):
+        c = self._cur
+        addr = self.w.append(data, align=8 if c["base"] is None else 1)
+        if c["base"] is None:
+            c["base"] = addr
+        elif addr != c["base"] + c["offsets"][-1]:
+            raise RuntimeError("H5CohortWriter: the chunks of a group must follow each other in the file")
+        base = c["offsets"][-1]
+        c["offsets"].extend(int(base + o) for o in offsets[1:])
+        c["raw_bytes"] += int(raw_bytes)
+
+    add_variants = StoreWriter.add_variants
+    add_chrom_runs = StoreWriter.add_chrom_runs
+
+    def end_group(self):
+        c = self._cur
+        S, sc, vc = len(self.meta["samples"]), self.meta["sc"], self.meta["vc"]
+        g = dict(n_variants=c["n_variants"], n_vcol=-(-c["n_variants"] // vc), n_scol=-(-max(S, 1) // sc),
+                 n_chunks=len(c["offsets"]) - 1, compressed_bytes=c["offsets"][-1], raw_bytes=c["raw_bytes"])
+        self.meta["groups"][c["name"]] = g
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+        _h5_group_datasets(self.w, c["name"], self.meta, g, c["base"] if c["base"] is not None else self.w.pos, c["offsets"],
+                           cat(c["start"], np.uint32), cat(c["ref"], np.uint8), cat(c["alt"], np.uint8), c["runs"])
+        self._cur = None
+
+    def close(self):
+        if self.w is not None:
+            self._names()
+            self.w.close()
+            self.w = None
+
+
 def export_h5(store_path, h5_path, donor_records=False, ctx=None):
     """store directory -> one HDF5 file at the reference's output path (`OUT/{cohort}.h5`,
     /root/reference/src/haplohyped/vcf_to_h5.py:161), written natively (h5file.py; no h5py in this image):
@@ -238,10 +326,7 @@ def export_h5(store_path, h5_path, donor_records=False, ctx=None):
         raise ValueError("export_h5: filter 32001 stores Blosc-1 chunks; this store holds " + meta.get("chunk_format", "blosc2"))
     sc, vc, S = meta["sc"], meta["vc"], len(meta["samples"])
 
-    def strings(xs):
-        n = max([len(x.encode()) for x in xs] + [1])
-        return np.array([x.encode() for x in xs], dtype=f"S{n}")
-
+    strings = _h5_strings
     with H5Writer(h5_path) as w:
         w.add_array("/", "samples", strings(meta["samples"]))
         w.add_array("/", "donor_ids", strings(meta["donor_ids"]))
@@ -258,19 +343,8 @@ def export_h5(store_path, h5_path, donor_records=False, ctx=None):
                     a = w.append(buf, align=8 if base is None else 1)
                     base = a if base is None else base
             base = w.pos if base is None else base
-            ids = np.arange(len(off) - 1)
-            vcol, scol = ids // g["n_scol"], ids % g["n_scol"]
-            chunks = [((int(sci) * sc, int(vci) * vc, 0), base + int(o0), int(o1 - o0))
-                      for sci, vci, o0, o1 in zip(scol, vcol, off[:-1], off[1:])]
-            w.add_chunked(group, "genotype", (S, g["n_variants"], 2), np.int8, (sc, vc, 2), chunks, filter_id=FILTER_BLOSC,
-                          cd_values=blosc_cd_values(meta["typesize"], sc * vc * 2), filter_name=b"blosc")
-            w.add_array(group, "start", start.astype(np.uint32))
-            w.add_array(group, "stop", (start + 1).astype(np.uint32))
-            w.add_array(group, "ref", np.load(os.path.join(d, "ref.npy")).astype(np.uint8).view("S1"))
-            w.add_array(group, "alt", np.load(os.path.join(d, "alt.npy")).astype(np.uint8).view("S1"))
-            runs = json.load(open(os.path.join(d, "chrom_runs.json")))
-            w.add_array(group, "chrom_run_first", np.array([r[0] for r in runs], np.uint32))
-            w.add_array(group, "chrom_run_name", strings([r[1] for r in runs]) if runs else np.zeros(0, "S1"))
+            _h5_group_datasets(w, group, meta, g, base, off, start, np.load(os.path.join(d, "ref.npy")), np.load(os.path.join(d, "alt.npy")),
+                               json.load(open(os.path.join(d, "chrom_runs.json"))))
         if donor_records:
             import torch
             from .device import BLOSC1

@@ -96,13 +96,14 @@ def _default_stream():
     return stream_files
 
 
-def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=None, make_ctx=None):
+def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=None, make_ctx=None, h5_path=None):
     """the work of one rank: its chromosome files -> groups of the (partial) store at part_path, all through ONE
     ingest engine (pipeline.stream_files): while chromosome k is being encoded, the host threads already inflate k+1.
-    stream_fn / make_ctx exist so that the CPU test suite can drive the rank / merge logic without a GPU."""
+    stream_fn / make_ctx exist so that the CPU test suite can drive the rank / merge logic without a GPU.
+    h5_path: write OUT/{cohort}.h5 directly instead of a store (one rank, no store asked for: store.H5CohortWriter)."""
     from ._lib import BLOSC1      # filter 32001 = hdf5-blosc: Blosc-1 chunk framing
     from .device import DEFAULT_SC, DEFAULT_VC
-    from .store import StoreWriter
+    from .store import H5CohortWriter, StoreWriter
     stream_fn = stream_fn or _default_stream()
     real_device = make_ctx is None      # (decided before the default is filled in: a test's fake context has no GPU to ask)
     if make_ctx is None:
@@ -121,8 +122,12 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
             devices = None
     host = pin_rank(rank, world, device if real_device else None, conv.cores, devices=devices)
     ctx = make_ctx(device)
-    writer = StoreWriter(part_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=conv.cohort_name,
-                         donor_ids=[d for d in conv.donor_ids if d], chunk_format="blosc1")
+    if h5_path:
+        writer = H5CohortWriter(h5_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=conv.cohort_name,
+                                donor_ids=[d for d in conv.donor_ids if d])
+    else:
+        writer = StoreWriter(part_path, [], DEFAULT_SC, DEFAULT_VC, cohort_name=conv.cohort_name,
+                             donor_ids=[d for d in conv.donor_ids if d], chunk_format="blosc1")
     stats = {}
     jobs = [(os.path.join(conv.vcf_dir, f"chr{c}.filtered.vcf.gz"), f"chr{c}") for c in chromosomes]
 
@@ -309,9 +314,15 @@ class VCFtoHDF5Converter:
         world = max(1, min(int(world), max(len(chromosomes), 1)))
         if os.path.isdir(self.store_path):
             shutil.rmtree(self.store_path)
+        n_donors = len([d for d in self.donor_ids if d])
+        per_donor = self.donor_records if self.donor_records is not None else n_donors <= 32
+        # one GPU, no working store asked for, no per-donor datasets (those are made from the store): the chunks go straight
+        # into OUT/{cohort}.h5 as the engine hands them over — no store, no second copy of every chunk (HHGT_H5_DIRECT=0: the
+        # store + export path, which N workers and the per-donor datasets use)
+        direct = world == 1 and not self.keep_store and not per_donor and os.environ.get("HHGT_H5_DIRECT", "1") != "0"
         try:
             if world == 1:
-                self.stats_by_group = convert_rank(self, 0, 1, 0, chromosomes, self.store_path)
+                self.stats_by_group = convert_rank(self, 0, 1, 0, chromosomes, self.store_path, h5_path=self.h5_path if direct else None)
             else:
                 # one process per GPU, started before this process touches a device
                 import torch.multiprocessing as mp
@@ -328,16 +339,15 @@ class VCFtoHDF5Converter:
                     raise RuntimeError(f"vcf_to_h5: {len(bad)} of {world} GPU workers failed (exit codes {bad})")
                 self.stats_by_group = json.load(open(os.path.join(self.store_path, "ranks.json")))["groups"]
                 logger.info(f"{world} GPU workers: plan {cfg['plan']}")
-            n_donors = len([d for d in self.donor_ids if d])
-            per_donor = self.donor_records if self.donor_records is not None else n_donors <= 32
             if not per_donor:
                 logger.warning(f"{n_donors} donors: the per-donor datasets donor_{{id}}/chr_{{N}}/snp_data of the reference "
                                f"layout are NOT written into {self.h5_path} (they would repeat the variant table per donor); "
                                f"the cohort matrix chr_{{N}}/genotype holds every genotype and VCFH5Reader serves the "
                                f"per-donor records from it.  Set HHGT_DONOR_RECORDS=yes to write them anyway.")
-            export_h5(self.store_path, self.h5_path, donor_records=per_donor)   # OUT/{cohort}.h5 (h5py + hdf5plugin read it)
-            if not self.keep_store:
-                shutil.rmtree(self.store_path, ignore_errors=True)
+            if not direct:
+                export_h5(self.store_path, self.h5_path, donor_records=per_donor)   # OUT/{cohort}.h5 (h5py + hdf5plugin read it)
+                if not self.keep_store:
+                    shutil.rmtree(self.store_path, ignore_errors=True)
             logger.info(f"Total time taken: {time.time() - t0:.2f} seconds; wrote {self.h5_path}")
         finally:
             shutil.rmtree(self.tmp_dir, ignore_errors=True)

@@ -182,6 +182,15 @@ def test_converter_two_workers_one_gpu(tmp_path, golden_dir, fixture_golden):
     dflt = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "dflt"), samples, 2, 1, n_gpus=1)
     assert dflt.run() == dflt.h5_path and not os.path.exists(dflt.store_path)
     assert open(dflt.h5_path, "rb").read() == open(one.h5_path, "rb").read()
+    # without the per-donor datasets one GPU writes OUT/{cohort}.h5 directly (no store, no export): the same bytes as the
+    # export of a kept store
+    direct = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "direct"), samples, 2, 1, n_gpus=1, donor_records=False)
+    kept = VCFtoHDF5Converter("c", str(vcf_dir), str(tmp_path / "kept"), samples, 2, 1, n_gpus=1, donor_records=False, keep_store=True)
+    assert direct.run() == direct.h5_path and not os.path.exists(direct.store_path)
+    assert kept.run() == kept.h5_path and os.path.isdir(kept.store_path)
+    assert open(direct.h5_path, "rb").read() == open(kept.h5_path, "rb").read()
+    rec = VCFH5Reader(direct.h5_path).fetch_genotypes(names[2], 7)
+    assert np.array_equal(rec["phase1"], o7["G"][2, :, 0]) and np.array_equal(rec["phase2"], o7["G"][2, :, 1])
 
 
 def test_header_only_chromosome(ctx, tmp_path, fixture_golden):
