@@ -111,6 +111,52 @@ class H5Writer:
         self.pos += n
         return addr
 
+    def append_file(self, path, align=8):
+        """the bytes of the file at `path` (a store's chunks.bin) -> file address; copied inside the kernel where it can
+        (os.copy_file_range) by PAR_THREADS threads, through a buffer where it cannot.  An empty file appends nothing (no padding
+        either) and returns the current position."""
+        n = os.path.getsize(path)
+        if n == 0:
+            return self.pos
+        pad = -self.pos % align
+        if pad:
+            os.pwrite(self.fd, b"\0" * pad, self.pos)
+            self.pos += pad
+        addr = self.pos
+        src = os.open(path, os.O_RDONLY)
+
+        def piece(o, cnt):
+            done = 0
+            while done < cnt:
+                k = 0
+                if hasattr(os, "copy_file_range"):
+                    try:
+                        k = os.copy_file_range(src, self.fd, cnt - done, o + done, addr + o + done)
+                    except OSError:
+                        k = 0
+                if k <= 0:      # another file system, an old kernel: read + write
+                    buf = os.pread(src, min(cnt - done, 16 << 20), o + done)
+                    if not buf:
+                        raise IOError(f"h5file: {path} ended early")
+                    self._pwrite_all(self.fd, memoryview(buf), addr + o + done)
+                    k = len(buf)
+                done += k
+
+        try:
+            if n >= self.PAR_MIN and self.PAR_THREADS > 1:
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(self.PAR_THREADS)
+                step = -(-(-(-n // self.PAR_THREADS)) // 4096) * 4096
+                for fut in [self._pool.submit(piece, o, min(step, n - o)) for o in range(0, n, step)]:
+                    fut.result()
+            else:
+                piece(0, n)
+        finally:
+            os.close(src)
+        self.pos += n
+        return addr
+
     # ---- tree of names -----------------------------------------------------------------------------------------
     def _ensure_group(self, path):
         if path in self.groups:

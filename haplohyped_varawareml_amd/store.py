@@ -38,14 +38,25 @@ class StoreWriter:
     def begin_group(self, group):
         d = os.path.join(self.path, group)
         os.makedirs(d, exist_ok=True)
-        self._cur = dict(name=group, dir=d, f=open(os.path.join(d, "chunks.bin"), "wb"), offsets=[0],
+        self._cur = dict(name=group, dir=d, f=open(os.path.join(d, "chunks.bin"), "wb", buffering=0), offsets=[0],
                          start=[], ref=[], alt=[], runs=[], n_variants=0, raw_bytes=0)
 
     def add_chunks(self, data, offsets, raw_bytes):
         """data: bytes-like of concatenated framed chunks; offsets: uint64 relative offsets [k+1]"""
+        from .h5file import H5Writer
         c = self._cur
         base = c["offsets"][-1]
-        c["f"].write(memoryview(data))
+        mv = memoryview(data).cast("B")
+        n, fd = len(mv), c["f"].fileno()
+        if n >= H5Writer.PAR_MIN and H5Writer.PAR_THREADS > 1:     # large batches: several pwrite threads (see H5Writer.append)
+            if getattr(self, "_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(H5Writer.PAR_THREADS)
+            step = -(-(-(-n // H5Writer.PAR_THREADS)) // 4096) * 4096
+            for fut in [self._pool.submit(H5Writer._pwrite_all, fd, mv[o:o + step], base + o) for o in range(0, n, step)]:
+                fut.result()
+        else:
+            H5Writer._pwrite_all(fd, mv, base)
         c["offsets"].extend(int(base + o) for o in offsets[1:])
         c["raw_bytes"] += int(raw_bytes)
 
@@ -75,6 +86,9 @@ class StoreWriter:
         self._cur = None
 
     def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown()
+            self._pool = None
         json.dump(self.meta, open(os.path.join(self.path, "meta.json"), "w"), indent=1)
 
 
@@ -334,15 +348,7 @@ def export_h5(store_path, h5_path, donor_records=False, ctx=None):
             d = os.path.join(store_path, group)
             off = np.load(os.path.join(d, "offsets.npy")).astype(np.uint64)
             start = np.load(os.path.join(d, "start.npy"))
-            base = None
-            with open(os.path.join(d, "chunks.bin"), "rb") as f:      # one bulk copy of all chunk bytes
-                while True:
-                    buf = f.read(64 << 20)
-                    if not buf:
-                        break
-                    a = w.append(buf, align=8 if base is None else 1)
-                    base = a if base is None else base
-            base = w.pos if base is None else base
+            base = w.append_file(os.path.join(d, "chunks.bin"))       # one bulk copy of all chunk bytes
             _h5_group_datasets(w, group, meta, g, base, off, start, np.load(os.path.join(d, "ref.npy")), np.load(os.path.join(d, "alt.npy")),
                                json.load(open(os.path.join(d, "chrom_runs.json"))))
         if donor_records:
