@@ -1642,6 +1642,31 @@ extern "C" int hhgt_ingest_next(hhgt_ingest *g, hhgt_ingest_event *ev)
     return HHGT_OK;
 }
 
+// The event returned by the last hhgt_ingest_next keeps its buffers past the next call: the consumer writes a batch of
+// chunks to a file on another thread while it already takes the next event (round 4: the converter's run was the engine's
+// 0.2 s stretched to 0.7 by the consumer's writes).  The token names the slots; hhgt_ingest_release may come from any thread.
+extern "C" int hhgt_ingest_hold(hhgt_ingest *g, int *token)
+{
+    if (!g || !token) return HHGT_ERR_ARG;
+    if (!g->have_held) {
+        hhgt_set_error("hhgt_ingest_hold: no event is held (call it after hhgt_ingest_next, once per event)");
+        return HHGT_ERR_ARG;
+    }
+    *token = (g->held.out_slot + 1) | ((g->held.var_slot + 1) << 8);
+    g->have_held = false;
+    return HHGT_OK;
+}
+
+extern "C" int hhgt_ingest_release(hhgt_ingest *g, int token)
+{
+    if (!g || token < 0) return HHGT_ERR_ARG;
+    const int out = (token & 0xFF) - 1, var = ((token >> 8) & 0xFF) - 1;
+    if (out >= N_OUT || var >= N_VAR) return HHGT_ERR_ARG;
+    if (var >= 0) g->free_var.push(var);
+    if (out >= 0) g->free_out.push(out);
+    return HHGT_OK;
+}
+
 extern "C" void hhgt_ingest_close(hhgt_ingest *g)
 {
     if (!g) return;

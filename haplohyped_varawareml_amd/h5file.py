@@ -81,6 +81,9 @@ class H5Writer:
         self.pos = 2048
         self.groups = {"/": {}}              # group path -> {name: ("group", path) | ("dataset", header_addr)}
         self._pool = None
+        if self.PAR_THREADS > 1:             # (made here, not at first use: append and write_at may run on two threads)
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(self.PAR_THREADS)
 
     # ---- raw space ------------------------------------------------------------------------------------------
     @staticmethod
@@ -110,6 +113,31 @@ class H5Writer:
             self._pwrite_all(self.fd, mv, addr)
         self.pos += n
         return addr
+
+    def reserve(self, n, align=8):
+        """n bytes of the file for a later write_at (their place is fixed now, their bytes may arrive on another thread)"""
+        pad = -self.pos % align
+        if pad:
+            os.pwrite(self.fd, b"\0" * pad, self.pos)
+            self.pos += pad
+        addr = self.pos
+        self.pos += int(n)
+        return addr
+
+    def write_at(self, addr, data):
+        """the bytes of a reserve()d range; large ranges by PAR_THREADS threads.  Safe beside append() on another thread: the
+        two never share a range"""
+        mv = memoryview(data).cast("B")
+        n = len(mv)
+        if n >= self.PAR_MIN and self.PAR_THREADS > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self.PAR_THREADS)
+            step = -(-(-(-n // self.PAR_THREADS)) // 4096) * 4096
+            for fut in [self._pool.submit(self._pwrite_all, self.fd, mv[o:o + step], addr + o) for o in range(0, n, step)]:
+                fut.result()
+        else:
+            self._pwrite_all(self.fd, mv, addr)
 
     def append_file(self, path, align=8):
         """the bytes of the file at `path` (a store's chunks.bin) -> file address; copied inside the kernel where it can

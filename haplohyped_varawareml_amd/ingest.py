@@ -4,6 +4,7 @@ concurrently inside libhhgt.  Replaces the per-(donor, chromosome) loop body of
 /root/reference/src/haplohyped/vcf_to_h5.py:79-140 for all samples of a file at once."""
 import ctypes as C
 import gc
+import threading
 from collections import namedtuple
 
 import numpy as np
@@ -59,6 +60,8 @@ def _L():
         L.hhgt_ingest_add_memory.argtypes = [vp, vp, C.c_uint64, C.c_char_p]
         L.hhgt_ingest_finish.argtypes = [vp]
         L.hhgt_ingest_next.argtypes = [vp, C.POINTER(IngestEvent)]
+        L.hhgt_ingest_hold.argtypes = [vp, C.POINTER(C.c_int)]
+        L.hhgt_ingest_release.argtypes = [vp, C.c_int]
         L.hhgt_ingest_close.argtypes = [vp]
         L.hhgt_ingest_close.restype = None
         _bound = True
@@ -97,6 +100,8 @@ class Ingest:
         instead of inside the first input (include/hhgt_ingest.h)"""
         self.L = _L()
         self.ctx = ctx
+        self._hold_lock = threading.Lock()
+        self.h = None
         device_inflate = normalize_device_inflate(device_inflate)
         o = IngestOpts(int(sc), int(vc), int(typesize), int(blocksize), int(fmt), int(bool(sites_only)),
                        (2 if device_inflate == "auto" else int(device_inflate)), int(n_threads or 0), int(block_bytes or 0),
@@ -155,11 +160,24 @@ class Ingest:
             if ours:
                 gc.unfreeze()
 
+    def hold(self):
+        """the buffers behind the event just yielded stay valid until release(token) — from any thread — instead of until
+        the next event (hhgt_ingest_hold)"""
+        t = C.c_int(-1)
+        check(self.L.hhgt_ingest_hold(self.h, C.byref(t)))
+        return int(t.value)
+
+    def release(self, token):
+        with self._hold_lock:        # (a writer thread may release while another thread closes the engine)
+            if getattr(self, "h", None):
+                check(self.L.hhgt_ingest_release(self.h, int(token)))
+
     def close(self):
-        if getattr(self, "h", None):
-            self.L.hhgt_ingest_close(self.h)
-            self.h = None
-            self._keep = []
+        with self._hold_lock:
+            if getattr(self, "h", None):
+                self.L.hhgt_ingest_close(self.h)
+                self.h = None
+                self._keep = []
 
     def __enter__(self):
         return self

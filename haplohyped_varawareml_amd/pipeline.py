@@ -260,12 +260,15 @@ def peek_sample_count(path, limit=64 << 20):
 
 def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=None, n_threads=0, sites_only=False,
                  fmt=dev.BLOSC2, device_inflate=None, on_header=None, on_variants=None, on_columns=None, on_end=None,
-                 files_ahead=1, expect_samples=None, clevel=None):
+                 files_ahead=1, expect_samples=None, clevel=None, hold_columns=False):
     """Several inputs through ONE native ingest engine (csrc/ingest.hip): the inflate of the next file overlaps the
     encode of the current one, and nothing waits on the host between blocks.
     jobs: [(path_or_host_buffer, region)]; callbacks get the job index first:
         on_header(i, sample_names)   on_variants(i, start, ref, alt)   on_columns(i, RawColumns, n_cols, (bytes, offsets))
         on_end(i, FileStats)
+    hold_columns: on_columns gets a fifth argument `release` and the (bytes, offsets) views stay valid until it is called
+        (from any thread) instead of until the callback returns — a consumer that writes the chunks on another thread
+        (hhgt_ingest_hold; the engine has five chunk buffers, so at most four batches can be in flight behind the current one)
     -> [FileStats] in job order"""
     from .ingest import Columns, Header, Ingest, InputEnd, Variants
     stats = [FileStats() for _ in jobs]
@@ -281,14 +284,14 @@ def stream_files(ctx, jobs, sc=dev.DEFAULT_SC, vc=dev.DEFAULT_VC, block_bytes=No
         ctx.set_clevel(clevel)
     try:
         return _stream_files(ctx, jobs, stats, sc, vc, block_bytes, n_threads, sites_only, fmt, device_inflate, on_header, on_variants,
-                             on_columns, on_end, files_ahead, expect_samples)
+                             on_columns, on_end, files_ahead, expect_samples, hold_columns)
     finally:
         if hasattr(ctx, "set_clevel"):
             ctx.set_clevel(prev_clevel)
 
 
 def _stream_files(ctx, jobs, stats, sc, vc, block_bytes, n_threads, sites_only, fmt, device_inflate, on_header, on_variants, on_columns,
-                  on_end, files_ahead, expect_samples):
+                  on_end, files_ahead, expect_samples, hold_columns=False):
     from .ingest import Columns, Header, Ingest, InputEnd, Variants
     if expect_samples is None:     # the first file's header says how wide the cohort is: the engine sizes and pins at open
         first = next((src for src, _ in jobs if isinstance(src, (str, os.PathLike))), None)
@@ -313,7 +316,11 @@ def _stream_files(ctx, jobs, stats, sc, vc, block_bytes, n_threads, sites_only, 
                 if on_variants and len(ev.start):
                     on_variants(ev.input, ev.start, ev.ref, ev.alt)
             elif isinstance(ev, Columns):
-                if on_columns:
+                if on_columns and hold_columns:
+                    token = ing.hold()
+                    on_columns(ev.input, RawColumns(ev.raw_bytes), ev.n_cols, (ev.framed, ev.chunk_off),
+                               (lambda t=token: ing.release(t)))
+                elif on_columns:
                     on_columns(ev.input, RawColumns(ev.raw_bytes), ev.n_cols, (ev.framed, ev.chunk_off))
             elif isinstance(ev, InputEnd):
                 for k, v in ev.stats.items():

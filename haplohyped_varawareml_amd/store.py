@@ -267,6 +267,7 @@ class H5CohortWriter:
         self.w = H5Writer(h5_path)
         self._cur = None
         self._named = False
+        self._q = self._thread = self._err = None     # the writer thread of add_chunks(..., release=...)
 
     def _names(self):
         # /samples and /donor_ids first, as export_h5 writes them (the sample names arrive with the first header, before the
@@ -280,9 +281,22 @@ class H5CohortWriter:
         self._names()
         self._cur = dict(name=group, base=None, offsets=[0], start=[], ref=[], alt=[], runs=[], n_variants=0, raw_bytes=0)
 
-    def add_chunks(self, data, offsets, raw_bytes):
+    def add_chunks(self, data, offsets, raw_bytes, release=None):
+        """release (optional): `data` stays valid until release() is called — the bytes are then written by the writer thread
+        while the caller goes on (pipeline.stream_files(hold_columns=True)); without it they are written before this returns"""
         c = self._cur
-        addr = self.w.append(data, align=8 if c["base"] is None else 1)
+        if release is None:
+            addr = self.w.append(data, align=8 if c["base"] is None else 1)
+        else:
+            self._raise_pending()
+            addr = self.w.reserve(len(data), align=8 if c["base"] is None else 1)
+            if self._q is None:
+                import queue
+                import threading
+                self._q = queue.Queue()
+                self._thread = threading.Thread(target=self._write_loop, name="h5-cohort-writer", daemon=True)
+                self._thread.start()
+            self._q.put((addr, data, release))
         if c["base"] is None:
             c["base"] = addr
         elif addr != c["base"] + c["offsets"][-1]:
@@ -291,12 +305,41 @@ class H5CohortWriter:
         c["offsets"].extend(int(base + o) for o in offsets[1:])
         c["raw_bytes"] += int(raw_bytes)
 
+    def _write_loop(self):
+        while True:
+            item = self._q.get()
+            try:
+                if item is None:
+                    return
+                addr, data, release = item
+                try:
+                    if self._err is None:
+                        self.w.write_at(addr, data)
+                except BaseException as e:      # (kept for the caller's thread: _raise_pending)
+                    self._err = e
+                finally:
+                    release()
+            finally:
+                self._q.task_done()
+
+    def _drain(self):
+        if self._q is not None:
+            self._q.join()
+        self._raise_pending()
+
+    def _raise_pending(self):
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+
     add_variants = StoreWriter.add_variants
     add_chrom_runs = StoreWriter.add_chrom_runs
 
     def end_group(self):
         c = self._cur
         S, sc, vc = len(self.meta["samples"]), self.meta["sc"], self.meta["vc"]
+        # (the group's index and tables go behind its chunks in the file: reserve() has fixed the chunks' places, the writer
+        # thread may still be filling them — nothing below reads them)
         g = dict(n_variants=c["n_variants"], n_vcol=-(-c["n_variants"] // vc), n_scol=-(-max(S, 1) // sc),
                  n_chunks=len(c["offsets"]) - 1, compressed_bytes=c["offsets"][-1], raw_bytes=c["raw_bytes"])
         self.meta["groups"][c["name"]] = g
@@ -307,6 +350,13 @@ class H5CohortWriter:
 
     def close(self):
         if self.w is not None:
+            try:
+                self._drain()
+            finally:
+                if self._q is not None:
+                    self._q.put(None)
+                    self._thread.join()
+                    self._q = self._thread = None
             self._names()
             self.w.close()
             self.w = None

@@ -156,9 +156,13 @@ def convert_rank(conv, rank, world, device, chromosomes, part_path, stream_fn=No
 
     try:
         if jobs:
+            extra = {}
+            if h5_path and real_device:      # the .h5 is written behind the engine: the chunk buffers are held until they are on file
+                extra["hold_columns"] = True
             stream_fn(ctx, jobs, sc=writer.meta["sc"], vc=writer.meta["vc"], n_threads=host["n_threads"], fmt=BLOSC1,
                       on_header=on_header, on_variants=lambda i, a, b, c: writer.add_variants(a, b, c),
-                      on_columns=lambda i, g, n, framed: writer.add_chunks(framed[0], framed[1], g.numel()), on_end=on_end)
+                      on_columns=(lambda i, g, n, framed, release=None: writer.add_chunks(framed[0], framed[1], g.numel(), **({"release": release} if release else {}))),
+                      on_end=on_end, **extra)
         writer.close()
     finally:
         if hasattr(ctx, "close"):

@@ -101,6 +101,12 @@ int hhgt_ingest_finish(hhgt_ingest *g);
 /* Next event, in order.  Blocks.  Pointers stay valid until the next hhgt_ingest_next / hhgt_ingest_close call.
  * On an error (first failing stage wins) returns its code; the engine is then finished. */
 int hhgt_ingest_next(hhgt_ingest *g, hhgt_ingest_event *ev);
+/* Keep the buffers of the event hhgt_ingest_next returned last beyond the next call (a consumer that writes a batch of
+ * chunks to a file on another thread while it takes the next event): *token names them, hhgt_ingest_release(token) gives
+ * them back, from any thread.  The engine has 5 chunk buffers and 6 variant-table buffers: a consumer that holds them all
+ * gets no further event until it releases one.  Once per event; an event without buffers gives a token that releases nothing. */
+int hhgt_ingest_hold(hhgt_ingest *g, int *token);
+int hhgt_ingest_release(hhgt_ingest *g, int token);
 void hhgt_ingest_close(hhgt_ingest *g);
 
 #ifdef __cplusplus

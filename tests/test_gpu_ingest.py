@@ -305,3 +305,40 @@ def test_device_and_host_inputs_alternate_in_one_engine(ctx, tmp_path):
         check_against_oracle(res[k], text, S, f"chr{k + 1}", sc, vc, runs=[(0, f"chr{k + 1}")])
     dev_inputs = [k for k in res if res[k]["stats"]["device_inflate"]]
     assert dev_inputs == [0, 2, 5] and all(res[k]["stats"]["n_blocks"] >= 2 for k in dev_inputs)
+
+
+def test_held_chunk_buffers_outlive_later_events(ctx, tmp_path):
+    """hhgt_ingest_hold: the chunk bytes of a Columns event stay intact while later events are taken, until the token is
+    released (from another thread, as the converter's writer thread does); decoded only then, against the oracle"""
+    import threading
+    S, V, sc, vc = 150, 20000, 64, 512
+    tab = synth.variant_table(41, V, S)
+    text, _ = synth.render_fixed_numpy("chr9", tab, S, seed=41)
+    p = str(tmp_path / "chr9.filtered.vcf.gz")
+    write_bgzf(p, text, level=6)
+    chunks, held = [], []
+
+    def settle(k):      # decode what was held k events ago, then give the buffers back on another thread
+        while len(held) > k:
+            framed, off, token = held.pop(0)
+            for i in range(len(off) - 1):
+                chunks.append(oracle.blosc_decompress(framed[int(off[i]):int(off[i + 1])]).copy())
+            t = threading.Thread(target=ing.release, args=(token,))
+            t.start()
+            t.join()
+
+    n_cols = 0
+    with Ingest(ctx, sc=sc, vc=vc, fmt=dev.BLOSC1, block_bytes=1 << 20, n_threads=2) as ing:
+        ing.add_file(p, "chr9")
+        ing.finish()
+        for ev in ing.events():
+            if isinstance(ev, Columns):
+                held.append((ev.framed, ev.chunk_off.copy(), ing.hold()))
+                n_cols += ev.n_cols
+                settle(3)          # up to three batches stay held while the next events are taken
+        settle(0)
+    o = oracle.vcf_encode(text, S, region="chr9")
+    want = tiled_expected(o["G"], S, o["n_kept"], sc, vc)
+    assert n_cols == -(-o["n_kept"] // vc) and len(chunks) == len(want)
+    for k, (a, b) in enumerate(zip(chunks, want)):
+        assert np.array_equal(a, b), f"chunk {k}"
