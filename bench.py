@@ -884,7 +884,7 @@ def main():
         sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_lz4_sq.txt")))
         mix = ""
         try:   # instruction mix per 4 KiB plane from the newest committed SQ-counter pass (a separate rocprofv3 --pmc run)
-            line = next(l for l in open(sq[-1]) if l.startswith("k_lz4_bitplanes<2, true, false"))
+            line = next(l for l in open(sq[-1]) if l.startswith(("k_lz4_bitplanes_uni<2, false>", "k_lz4_bitplanes<2, true, false")))
             w = json.loads(line[line.index("{"):])
             mix = (f"{w['SQ_INSTS_VALU'] / 1e3:.2f} k vector + {w['SQ_INSTS_SALU'] / 1e3:.2f} k scalar + {w['SQ_INSTS_LDS'] / 1e3:.2f} k LDS "
                    f"instructions per 4 KiB plane at 7 waves per SIMD ({os.path.basename(sq[-1])}); ")

@@ -84,6 +84,9 @@ template <bool EXC> struct BpCfg {
 #else
 #define BP_MARK(name)
 #endif
+#ifndef BP_SKIP
+#define BP_SKIP 0   // development: 1 no emission, 2 no layout either, 3 no selection, 4 no window loop, 5 phase A only (invalid output; timing only)
+#endif
 #define BP_MFLIMIT (BP_N - 12)
 #define BP_MATCHLIMIT (BP_N - 5)
 
@@ -329,144 +332,22 @@ __device__ __forceinline__ BpOut bp_emit_batch(LDS &S, const uint32_t *bm, uint8
     return BpOut{prev_end, gop, sop};
 }
 
-// grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
-// DEPTH = candidates tried per one along the hash chain (1: the table's entry only; 0: no hash matches at all,
-// offset-1 runs only — the fastest level)
-// PLANES: src is the bit-plane form of the matrix (include/hhgt.h, tile-major: common.h; written by k_encode_planes): the
-// wave's bit map is 16 pieces of 32 bytes it gathers as they are (one load instruction: lane l takes 8 bytes of tile
-// l / 4), and a set EXC bit is what "a byte > 1" was.  The pieces of four neighbouring sample rows share a 128-byte
-// line, so the blocks are dealt to the workgroups in an XCD-aware order: of 64 consecutive workgroups the eight that land
-// on one XCD (round robin) take eight consecutive blocks — one L2 fetches each line once.
-// EXC (with PLANES): the exception-aware instantiation — planes whose bytes are 0, 1 or 0xF7 (missing calls; config 4).
-// On a fixed grid every wave scans the stream sizes of its plane, 64 blocks per load, and codes the streams the plain
-// instantiation left marked (csize = 0xFFFFFFFF; a list of marked blocks built by atomic adds on one counter cost more than
-// the coding itself when every plane is marked: 6 ms for config 4's 537 k blocks); the bit map is the map of NONZERO bytes, a second map says which of them are 0xF7, every one
-// carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
-// Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
-template <int DEPTH, bool PLANES, bool EXC, bool LAZY = false>
-__global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
-                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
-                                                          uint32_t *__restrict__ flags, uint32_t tag)
+// One plane, from its bit map(s) in registers to its stream (or its mark): everything behind the loads.  FLAG: which word of
+// `flags` says "this call left a mark" for the launch that scans next; WRITE_MARK: the mark is written here (the scanning
+// exception-aware launch finds it in place already).
+template <int DEPTH, bool EXC, bool LAZY, int FLAG, bool WRITE_MARK, typename LDS>
+__device__ __forceinline__ void bp_code_plane(LDS &S, uint32_t wlo, uint32_t whi, uint32_t xlo, uint32_t xhi, bool nonbinary, uint32_t bid,
+                                              uint32_t wave, uint32_t lane, uint8_t *__restrict__ scratch, uint64_t slot_bytes,
+                                              uint32_t *__restrict__ csize, uint32_t *__restrict__ flags, uint32_t tag)
 {
-    static_assert(!EXC || PLANES, "the exception-aware coder reads bit planes");
-    // flags (may be null): flags[0] == tag <=> the plain instantiation of THIS call left a stream marked, flags[1] == tag <=> the
-    // exception-aware one did.  The scanning launches behind (this kernel with EXC, lz4.hip's kernel in scan mode) look at the
-    // word first and are gone if nobody marked anything — on the headline cohort that is every call, and the two scans were
-    // 48 us of each shard's chain (r04b_bench_kernel_stats.csv).  A tag per call instead of a flag somebody has to clear.
-    if (EXC && flags && __builtin_nontemporal_load(flags) != tag) return;
     constexpr bool CHAIN = DEPTH > 1;
-    __shared__ BpLds<CHAIN, EXC> lds[2];
-    __shared__ uint32_t nonbin[2][2];
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    // EXC: `return` inside the body means "next marked block" (the two waves of a workgroup are independent there)
-#define BP_DONE()               \
-    do {                        \
-        if (EXC) goto bp_next;  \
-        else return;            \
-    } while (0)
-    for (uint32_t b0 = EXC ? blockIdx.x * 64u : 0u; b0 < (EXC ? n_blocks : 1u); b0 += EXC ? gridDim.x * 64u : 1u) {
-    unsigned long long todo = 1ull;
-    if (EXC) {   // which of the 64 blocks from b0 on still have this wave's stream marked
-        const uint32_t bb = b0 + lane;
-        todo = __builtin_amdgcn_ballot_w64(bb < n_blocks && csize[(uint64_t)bb * 2u + wave] == 0xFFFFFFFFu);
-    }
-    while (todo != 0ull) {   // (wave-uniform)
-    {
-    const uint32_t bid = EXC ? b0 + (uint32_t)__builtin_ctzll(todo)
-                             : PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
-    todo &= todo - 1ull;
-    if (PLANES && !EXC && bid >= n_blocks) return;   // (the grid is rounded up to whole groups of 64)
-    uint32_t xlo = 0, xhi = 0;   // EXC: the lane's 64 positions of the missing-call map
-    uint32_t wlo, whi;
-    bool nonbinary;
-    if (PLANES) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        uint64_t col;
-        uint32_t row, bi;
-        planes_block(pg, bid, &col, &row, &bi);
-        const u32x2 *pl = reinterpret_cast<const u32x2 *>(src + planes_piece(pg, col, bi * 16u + (lane >> 2), wave, row)) + (lane & 3u);
-        const u32x2 one = *pl, exc = *(pl + (uint64_t)pg.S_pad * 8ull);   // EXC: two kind-planes (S_pad * 32 bytes each) further
-        wlo = one.x;
-        whi = one.y;
-        lds[wave].bm[2u * lane] = wlo;
-        lds[wave].bm[2u * lane + 1u] = whi;
-        if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
-        if (EXC) {
-            // (ONE, EXC) = (0, 1): a call beyond 0 / 1 / missing, its byte lives in the int8 matrix — not this coder's
-            nonbinary = __builtin_amdgcn_ballot_w64(((exc.x & ~one.x) | (exc.y & ~one.y)) != 0u) != 0ull;
-            xlo = exc.x;
-            xhi = exc.y;
-            lds[wave].xm[2u * lane] = xlo;
-            lds[wave].xm[2u * lane + 1u] = xhi;
-            if (lane < 4u) lds[wave].xm[128u + lane] = 0u;
-            if (lane < 24u) lds[wave].cls[lane] = 0u;
-        } else {
-            nonbinary = __builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) != 0ull;
-        }
-    } else {
-    const uint8_t *blk = src + (uint64_t)bid * 8192u;
-
-    // ---- phase A: wave r packs the bits of block bytes [4096 r, 4096 r + 4096) for BOTH planes (byte-shuffle fused:
-    //      even bytes are plane 0, odd bytes plane 1).  Load k of a lane is the 16 bytes at 1024 k + 16 lane: every load
-    //      instruction of the wave covers one contiguous KiB (the first version gave each lane 64 contiguous bytes, i.e.
-    //      four instructions that each touched all 64 lines of the half block; FETCH_SIZE is the same either way — the L2
-    //      absorbed the repeats — but the step is 1.5 % faster with this form).
-    //      16 bytes = 8 positions of each plane = one BYTE of each bit map, at byte 256 r + 64 k + lane.
-    {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 *p = reinterpret_cast<const u32x4 *>(blk + 4096u * wave + 16u * lane);
-        u32x4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(p + 64 * k);   // streamed once
-        uint32_t orall = 0;
-        uint8_t *bm0 = reinterpret_cast<uint8_t *>(lds[0].bm) + 256u * wave + lane;
-        uint8_t *bm1 = reinterpret_cast<uint8_t *>(lds[1].bm) + 256u * wave + lane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-            uint32_t acc0 = 0, acc1 = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t x = d[i];
-                orall |= x;
-                const uint32_t xm = x & 0x01010101u;   // (a byte > 1 in one plane must not leak into the other plane's bits)
-                const uint32_t y = xm | (xm >> 15);    // bits 0,1: plane-0 bytes; bits 8,9: plane-1 bytes
-                acc0 |= (y & 3u) << (2 * i);
-                acc1 |= ((y >> 8) & 3u) << (2 * i);
-            }
-            bm0[64 * k] = (uint8_t)acc0;
-            bm1[64 * k] = (uint8_t)acc1;
-        }
-        const uint32_t nb0 = orall & 0x00FE00FEu, nb1 = orall & 0xFE00FE00u;   // a byte > 1 somewhere in plane 0 / plane 1
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nb0 != 0u), b1 = __builtin_amdgcn_ballot_w64(nb1 != 0u);
-        if (lane == 0) {
-            nonbin[wave][0] = b0 != 0ull;
-            nonbin[wave][1] = b1 != 0ull;
-        }
-        if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
-    }
-    __syncthreads();
-    wlo = lds[wave].bm[2u * lane];
-    whi = lds[wave].bm[2u * lane + 1u];
-    nonbinary = (nonbin[0][wave] | nonbin[1][wave]) != 0u;
-    }
-    BP_MARK("A_done");
-#ifndef BP_SKIP
-#define BP_SKIP 0   // development: 1 no emission, 2 no layout either, 3 no selection, 4 no window loop, 5 phase A only (invalid output; timing only)
-#endif
     uint32_t sink = 0;
-    if (BP_SKIP >= 5) {
-        if (lane == 0) csize[(uint64_t)bid * 2u + wave] = lds[wave].bm[5] & 1u;
-        BP_DONE();
-    }
-
     // ---- phase B: wave w codes plane w
     // The lanes of the wave exchange data through S with no barrier in between: the LDS executes a wave's instructions in
     // order.  What the COMPILER must not do is move a lane's read in front of another lane's earlier write; every such
     // hand-over below is an access whose address it cannot tell apart from the lane's own writes, and BP_FENCE marks
     // the phase boundaries for good measure.  (volatile pointers would also do — and turn every access into a
     // serialised flat load with its own wait, which made this kernel 2x slower than it had to be.)
-    BpLds<CHAIN, EXC> &S = lds[wave];
     uint32_t *bm = S.bm;
     uint16_t *P = S.P;
     uint16_t *wpre = S.wpre;
@@ -479,9 +360,8 @@ __global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitp
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (nonbinary || m > BpCfg<EXC>::MAXONES) {
         // (the flag: read first — the line sits in the L2 and after the first few marking waves of an XCD it holds the tag)
-        if (lane == 0 && flags && flags[EXC ? 1 : 0] != tag) flags[EXC ? 1 : 0] = tag;
-        if (EXC) BP_DONE();   // stays marked: the byte-wise kernel scans for it next
-        if (lane == 0) csize[sidx] = 0xFFFFFFFFu;   // left to the next coder
+        if (lane == 0 && flags && flags[FLAG] != tag) flags[FLAG] = tag;
+        if (lane == 0 && WRITE_MARK) csize[sidx] = 0xFFFFFFFFu;   // left to the next coder (the scanning exception-aware launch finds the mark there already)
         return;
     }
     BP_MARK("scan_done");
@@ -532,7 +412,7 @@ __global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitp
     BP_MARK("plist_done");
     if (BP_SKIP >= 4) {
         if (lane == 0) csize[sidx] = P[m] & 1u;
-        BP_DONE();
+        return;
     }
     uint32_t gop = 0, sop = 0, prev_end = 0, qn = 0;   // bytes written to global / staged; end of the last sequence; queued coded ones
     int cur = -1;   // next one to be coded (the virtual one in front of the stream first)
@@ -806,7 +686,7 @@ __global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitp
     BP_MARK("loop_done");
     if (BP_SKIP >= 1) {
         if (lane == 0) csize[sidx] = (prev_end + sink) & 0xFFFu;
-        BP_DONE();
+        return;
     }
     // ---- last literals
     {
@@ -861,11 +741,180 @@ __global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitp
     }
 #endif
     if (lane == 0) csize[sidx] = op;
+}
+
+// grid = number of 8 KiB blocks; 128 threads: wave w codes byte plane w of the block
+// DEPTH = candidates tried per one along the hash chain (1: the table's entry only; 0: no hash matches at all,
+// offset-1 runs only — the fastest level)
+// PLANES: src is the bit-plane form of the matrix (include/hhgt.h, tile-major: common.h; written by k_encode_planes): the
+// wave's bit map is 16 pieces of 32 bytes it gathers as they are (one load instruction: lane l takes 8 bytes of tile
+// l / 4), and a set EXC bit is what "a byte > 1" was.  The pieces of four neighbouring sample rows share a 128-byte
+// line, so the blocks are dealt to the workgroups in an XCD-aware order: of 64 consecutive workgroups the eight that land
+// on one XCD (round robin) take eight consecutive blocks — one L2 fetches each line once.
+// EXC (with PLANES): the exception-aware instantiation — planes whose bytes are 0, 1 or 0xF7 (missing calls; config 4).
+// On a fixed grid every wave scans the stream sizes of its plane, 64 blocks per load, and codes the streams the plain
+// instantiation left marked (csize = 0xFFFFFFFF; a list of marked blocks built by atomic adds on one counter cost more than
+// the coding itself when every plane is marked: 6 ms for config 4's 537 k blocks); the bit map is the map of NONZERO bytes, a second map says which of them are 0xF7, every one
+// carries that bit as its class, and two ones only agree if their classes do (tools/sim/gapenc_ref.c states the rules).
+// Streams it cannot code either (a call beyond 0 / 1 / missing, too many nonzero bytes) stay marked for the byte-wise kernel.
+template <int DEPTH, bool PLANES, bool EXC, bool LAZY = false>
+__global__ __launch_bounds__(128, EXC ? BP_WAVES_EXC : BP_WAVES) void k_lz4_bitplanes(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
+                                                          uint8_t *__restrict__ scratch, uint64_t slot_bytes, uint32_t *__restrict__ csize,
+                                                          uint32_t *__restrict__ flags, uint32_t tag)
+{
+    static_assert(!EXC || PLANES, "the exception-aware coder reads bit planes");
+    // flags (may be null): flags[0] == tag <=> the plain instantiation of THIS call left a stream marked, flags[1] == tag <=> the
+    // exception-aware one did.  The scanning launches behind (this kernel with EXC, lz4.hip's kernel in scan mode) look at the
+    // word first and are gone if nobody marked anything — on the headline cohort that is every call, and the two scans were
+    // 48 us of each shard's chain (r04b_bench_kernel_stats.csv).  A tag per call instead of a flag somebody has to clear.
+    if (EXC && flags && __builtin_nontemporal_load(flags) != tag) return;
+    constexpr bool CHAIN = DEPTH > 1;
+    __shared__ BpLds<CHAIN, EXC> lds[2];
+    __shared__ uint32_t nonbin[2][2];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    // (EXC: the two waves of a workgroup are independent; each walks the marked streams of its plane)
+    for (uint32_t b0 = EXC ? blockIdx.x * 64u : 0u; b0 < (EXC ? n_blocks : 1u); b0 += EXC ? gridDim.x * 64u : 1u) {
+    unsigned long long todo = 1ull;
+    if (EXC) {   // which of the 64 blocks from b0 on still have this wave's stream marked
+        const uint32_t bb = b0 + lane;
+        todo = __builtin_amdgcn_ballot_w64(bb < n_blocks && csize[(uint64_t)bb * 2u + wave] == 0xFFFFFFFFu);
     }
-bp_next:;
+    while (todo != 0ull) {   // (wave-uniform)
+    {
+    const uint32_t bid = EXC ? b0 + (uint32_t)__builtin_ctzll(todo)
+                             : PLANES ? ((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u)) : blockIdx.x;
+    todo &= todo - 1ull;
+    if (PLANES && !EXC && bid >= n_blocks) return;   // (the grid is rounded up to whole groups of 64)
+    uint32_t xlo = 0, xhi = 0;   // EXC: the lane's 64 positions of the missing-call map
+    uint32_t wlo, whi;
+    bool nonbinary;
+    if (PLANES) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        uint64_t col;
+        uint32_t row, bi;
+        planes_block(pg, bid, &col, &row, &bi);
+        const u32x2 *pl = reinterpret_cast<const u32x2 *>(src + planes_piece(pg, col, bi * 16u + (lane >> 2), wave, row)) + (lane & 3u);
+        const u32x2 one = *pl, exc = *(pl + (uint64_t)pg.S_pad * 8ull);   // EXC: two kind-planes (S_pad * 32 bytes each) further
+        wlo = one.x;
+        whi = one.y;
+        lds[wave].bm[2u * lane] = wlo;
+        lds[wave].bm[2u * lane + 1u] = whi;
+        if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
+        if (EXC) {
+            // (ONE, EXC) = (0, 1): a call beyond 0 / 1 / missing, its byte lives in the int8 matrix — not this coder's
+            nonbinary = __builtin_amdgcn_ballot_w64(((exc.x & ~one.x) | (exc.y & ~one.y)) != 0u) != 0ull;
+            xlo = exc.x;
+            xhi = exc.y;
+            lds[wave].xm[2u * lane] = xlo;
+            lds[wave].xm[2u * lane + 1u] = xhi;
+            if (lane < 4u) lds[wave].xm[128u + lane] = 0u;
+            if (lane < 24u) lds[wave].cls[lane] = 0u;
+        } else {
+            nonbinary = __builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) != 0ull;
+        }
+    } else {
+    const uint8_t *blk = src + (uint64_t)bid * 8192u;
+
+    // ---- phase A: wave r packs the bits of block bytes [4096 r, 4096 r + 4096) for BOTH planes (byte-shuffle fused:
+    //      even bytes are plane 0, odd bytes plane 1).  Load k of a lane is the 16 bytes at 1024 k + 16 lane: every load
+    //      instruction of the wave covers one contiguous KiB (the first version gave each lane 64 contiguous bytes, i.e.
+    //      four instructions that each touched all 64 lines of the half block; FETCH_SIZE is the same either way — the L2
+    //      absorbed the repeats — but the step is 1.5 % faster with this form).
+    //      16 bytes = 8 positions of each plane = one BYTE of each bit map, at byte 256 r + 64 k + lane.
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(blk + 4096u * wave + 16u * lane);
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(p + 64 * k);   // streamed once
+        uint32_t orall = 0;
+        uint8_t *bm0 = reinterpret_cast<uint8_t *>(lds[0].bm) + 256u * wave + lane;
+        uint8_t *bm1 = reinterpret_cast<uint8_t *>(lds[1].bm) + 256u * wave + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            uint32_t acc0 = 0, acc1 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t x = d[i];
+                orall |= x;
+                const uint32_t xm = x & 0x01010101u;   // (a byte > 1 in one plane must not leak into the other plane's bits)
+                const uint32_t y = xm | (xm >> 15);    // bits 0,1: plane-0 bytes; bits 8,9: plane-1 bytes
+                acc0 |= (y & 3u) << (2 * i);
+                acc1 |= ((y >> 8) & 3u) << (2 * i);
+            }
+            bm0[64 * k] = (uint8_t)acc0;
+            bm1[64 * k] = (uint8_t)acc1;
+        }
+        const uint32_t nb0 = orall & 0x00FE00FEu, nb1 = orall & 0xFE00FE00u;   // a byte > 1 somewhere in plane 0 / plane 1
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nb0 != 0u), b1 = __builtin_amdgcn_ballot_w64(nb1 != 0u);
+        if (lane == 0) {
+            nonbin[wave][0] = b0 != 0ull;
+            nonbin[wave][1] = b1 != 0ull;
+        }
+        if (lane < 4u) lds[wave].bm[128u + lane] = 0u;
+    }
+    __syncthreads();
+    wlo = lds[wave].bm[2u * lane];
+    whi = lds[wave].bm[2u * lane + 1u];
+    nonbinary = (nonbin[0][wave] | nonbin[1][wave]) != 0u;
+    }
+    BP_MARK("A_done");
+    if (BP_SKIP >= 5) {
+        if (lane == 0) csize[(uint64_t)bid * 2u + wave] = lds[wave].bm[5] & 1u;
+        continue;
+    }
+
+    bp_code_plane<DEPTH, EXC, LAZY, EXC ? 1 : 0, !EXC>(lds[wave], wlo, whi, xlo, xhi, nonbinary, bid, wave, lane, scratch, slot_bytes, csize, flags, tag);
     }
     }
-#undef BP_DONE
+    }
+}
+
+// The plain and the exception-aware coder in ONE launch over bit planes (round 4): a wave looks at its plane's missing-call map
+// and takes the one or the other path (wave-uniform; both are the instantiations above, inlined).  What it replaces is the plain
+// launch marking every plane that holds a missing call for a second, scanning launch — on config 4, where every plane does,
+// 0.4 ms of reading all planes for nothing.  Planes neither can code (a call beyond 0 / 1 / missing, too many nonzero bytes) are
+// marked for the byte-wise kernel as before (flags[0]).
+template <int DEPTH, bool LAZY>
+__global__ __launch_bounds__(128, BP_WAVES) void k_lz4_bitplanes_uni(const uint8_t *__restrict__ src, PlanesGeom pg, uint32_t n_blocks,
+                                                                      uint8_t *__restrict__ scratch, uint64_t slot_bytes,
+                                                                      uint32_t *__restrict__ csize, uint32_t *__restrict__ flags, uint32_t tag)
+{
+    constexpr bool CHAIN = DEPTH > 1;
+    union BpBoth {
+        BpLds<CHAIN, false> p;
+        BpLds<CHAIN, true> x;
+    };
+    __shared__ BpBoth lds[2];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    const uint32_t bid = (blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u);   // (XCD-aware order, as above)
+    if (bid >= n_blocks) return;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint64_t col;
+    uint32_t row, bi;
+    planes_block(pg, bid, &col, &row, &bi);
+    const u32x2 *pl = reinterpret_cast<const u32x2 *>(src + planes_piece(pg, col, bi * 16u + (lane >> 2), wave, row)) + (lane & 3u);
+    const u32x2 one = *pl, exc = *(pl + (uint64_t)pg.S_pad * 8ull);
+    if (__builtin_amdgcn_ballot_w64((exc.x | exc.y) != 0u) == 0ull) {   // no missing call in this plane: the plain coder
+        BpLds<CHAIN, false> &S = lds[wave].p;
+        S.bm[2u * lane] = one.x;
+        S.bm[2u * lane + 1u] = one.y;
+        if (lane < 4u) S.bm[128u + lane] = 0u;
+        bp_code_plane<DEPTH, false, LAZY, 0, true>(S, one.x, one.y, 0u, 0u, false, bid, wave, lane, scratch, slot_bytes, csize, flags, tag);
+    } else {
+        BpLds<CHAIN, true> &S = lds[wave].x;
+        // (ONE, EXC) = (0, 1): a call beyond 0 / 1 / missing, its byte lives in the int8 matrix — not this coder's
+        const bool nonbinary = __builtin_amdgcn_ballot_w64(((exc.x & ~one.x) | (exc.y & ~one.y)) != 0u) != 0ull;
+        S.bm[2u * lane] = one.x;
+        S.bm[2u * lane + 1u] = one.y;
+        if (lane < 4u) S.bm[128u + lane] = 0u;
+        S.xm[2u * lane] = exc.x;
+        S.xm[2u * lane + 1u] = exc.y;
+        if (lane < 4u) S.xm[128u + lane] = 0u;
+        if (lane < 24u) S.cls[lane] = 0u;
+        bp_code_plane<DEPTH, true, LAZY, 0, true>(S, one.x, one.y, exc.x, exc.y, nonbinary, bid, wave, lane, scratch, slot_bytes, csize, flags, tag);
+    }
 }
 
 // depth: candidates per one; + 0x100: with the lazy rule (instantiated for 12 candidates — clevel 9 — and, for measurements, 2)
@@ -886,13 +935,19 @@ int launch_lz4_bitplanes(const uint8_t *d_src, bool planes, PlanesGeom pg, uint6
     // the exception-aware instantiation scans for the streams the plain one marked, on a grid that fills the chip
     // (HHGT_LZ4_EXC=0: every marked stream goes to the byte-wise kernel, as before round 3)
     static const bool exc_env = !(getenv("HHGT_LZ4_EXC") && atoi(getenv("HHGT_LZ4_EXC")) == 0);
+    // planes: one launch in which every wave takes the plain or the exception-aware path by its plane's missing-call map
+    // (HHGT_LZ4_UNI=0: the plain launch marks, the exception-aware one scans for the marks — rounds 3 and 4a-c)
+    static const bool uni_env = exc_env && !(getenv("HHGT_LZ4_UNI") && atoi(getenv("HHGT_LZ4_UNI")) == 0);
     const uint32_t exc_grid = (uint32_t)((n_blocks + 63) / 64 < 256u * 14u ? (n_blocks + 63) / 64 : 256u * 14u);
 #define BP_LAUNCH2(D, PL, LZ)                                                                                               \
     hipLaunchKernelGGL((k_lz4_bitplanes<D, PL, false, LZ>), dim3(PL ? (uint32_t)((n_blocks + 63) / 64 * 64) : (uint32_t)n_blocks), dim3(128), lds_pad, st, \
                        d_src, pg, (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize, d_flags, tag)
 #define BP_LAUNCH(D, LZ)                                                                                                    \
     do {                                                                                                                    \
-        if (planes) {                                                                                                       \
+        if (planes && uni_env) {                                                                                            \
+            hipLaunchKernelGGL((k_lz4_bitplanes_uni<D, LZ>), dim3((uint32_t)((n_blocks + 63) / 64 * 64)), dim3(128), lds_pad, st, d_src, pg, \
+                               (uint32_t)n_blocks, d_scratch, (uint64_t)slot_bytes, d_csize, d_flags, tag);                 \
+        } else if (planes) {                                                                                                \
             BP_LAUNCH2(D, true, LZ);                                                                                        \
             if (exc_env) {                                                                                                  \
                 hipLaunchKernelGGL((k_lz4_bitplanes<D, true, true, LZ>), dim3(exc_grid), dim3(128), 0, st, d_src, pg, (uint32_t)n_blocks, d_scratch, \
