@@ -855,7 +855,7 @@ def main():
     b_whole = text_bytes + g_bytes + g_bytes + comp_bytes
     step_s = dt_max / args.steps
     moved_per_launch = moved.get(dom, alg[dom]) / max(len(shards), 1)
-    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_bitplanes", "encode": "k_encode_planes" if planes else "k_encode_tiles", "index": "k_index_hop",
+    roof = {"bound": "hbm", "kernel": {"lz4": "k_lz4_bitplanes_uni" if planes else "k_lz4_bitplanes", "encode": "k_encode_planes" if planes else "k_encode_tiles", "index": "k_index_hop",
                                        "frame": "k_frame_write"}.get(dom, dom),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             # what this build's kernel really moves per launch (planes in, streams out) over the same launch time: the figure

@@ -52,7 +52,7 @@ out = {
     "variants_per_pass": VARIANTS,
 }
 # the "lz4" stage is two launches per shard: the bit-plane coder, then the byte-wise coder over the streams it marked
-for name, kerns in (("lz4", ("k_lz4_bitplanes", "k_lz4_blocks")), ("encode", ("k_encode_tiles", "k_encode_planes")), ("index", ("k_index_newlines", "k_index_hop")),
+for name, kerns in (("lz4", ("k_lz4_bitplanes", "k_lz4_bitplanes_uni", "k_lz4_blocks")), ("encode", ("k_encode_tiles", "k_encode_planes")), ("index", ("k_index_newlines", "k_index_hop")),
                     ("frame", ("k_frame_write",)), ("fixed", ("k_parse_fixed",))):
     kerns = [k for k in kerns if k in f]
     if not kerns:
