@@ -327,3 +327,68 @@ def test_genotype_store_opens_an_h5_file_cpu(tmp_path):
         with h5file.H5Writer(bad) as w:
             w.add_array("/", "x", np.zeros(1, np.uint8))
         GenotypeStore(bad)
+
+
+def test_cohort_writer_equals_the_export_of_a_store(tmp_path):
+    """store.H5CohortWriter (the converter's direct path) against StoreWriter + export_h5 on the same batches of chunks:
+    byte-identical files — with the chunks written before add_chunks returns, and with them handed to the writer thread and
+    released afterwards (large batches go through the parallel pwrite path); an empty group among them"""
+    import threading
+    from oracle import oracle
+    from haplohyped_varawareml_amd.store import GenotypeStore, H5CohortWriter, StoreWriter, export_h5
+    S, sc, vc = 70, 64, 128
+    rng = np.random.default_rng(5)
+    samples = [f"S{i:03d}" for i in range(S)]
+    groups = {"chr_3": 300, "chr_5": 0, "chr_9": 4000}
+
+    def feed(w, release_log=None):
+        w.meta["samples"] = list(samples)
+        for gi, (group, V) in enumerate(groups.items()):
+            g_rng = np.random.default_rng(100 + gi)
+            G = (g_rng.random((S, max(V, 1), 2)) < 0.08).astype(np.int8)[:, :V]
+            w.begin_group(group)
+            start = np.sort(g_rng.integers(1, 1 << 24, V)).astype(np.uint32)
+            n_vcol = -(-V // vc)
+            for v0 in range(0, n_vcol, 7):                      # batches of up to 7 chunk columns, as the engine hands them over
+                parts, offs = [], [0]
+                for vci in range(v0, min(v0 + 7, n_vcol)):
+                    for si in range(0, S, sc):
+                        blk = np.zeros((sc, vc, 2), np.int8)
+                        sub = G[si:si + sc, vci * vc:(vci + 1) * vc]
+                        blk[:sub.shape[0], :sub.shape[1]] = sub
+                        ck = oracle.blosc_compress(blk.reshape(-1).view(np.uint8), 2, vc * 2, oracle.BLOSC1)
+                        parts.append(ck)
+                        offs.append(offs[-1] + ck.size)
+                data = np.concatenate(parts)
+                raw = (len(offs) - 1) * sc * vc * 2
+                if release_log is None:
+                    w.add_chunks(data, np.asarray(offs, np.uint64), raw)
+                else:
+                    ev = threading.Event()
+                    release_log.append(ev)
+                    w.add_chunks(data, np.asarray(offs, np.uint64), raw, release=ev.set)
+                a, b = v0 * vc, min((v0 + 7) * vc, V)
+                w.add_variants(start[a:b], np.full(b - a, ord("A"), np.uint8), np.full(b - a, ord("G"), np.uint8))
+            w.add_chrom_runs([(0, group.replace("_", ""))] if V else [])
+            w.end_group()
+        w.close()
+
+    store = str(tmp_path / "c.hhgt")
+    feed(StoreWriter(store, [], sc, vc, cohort_name="c", donor_ids=samples[:2], chunk_format="blosc1"))
+    export_h5(store, str(tmp_path / "exported.h5"))
+    feed(H5CohortWriter(str(tmp_path / "direct.h5"), [], sc, vc, cohort_name="c", donor_ids=samples[:2]))
+    log = []
+    old = h5file.H5Writer.PAR_MIN
+    h5file.H5Writer.PAR_MIN = 4096                               # the small batches of this test through the parallel writes too
+    try:
+        feed(H5CohortWriter(str(tmp_path / "behind.h5"), [], sc, vc, cohort_name="c", donor_ids=samples[:2]), release_log=log)
+    finally:
+        h5file.H5Writer.PAR_MIN = old
+    want = open(tmp_path / "exported.h5", "rb").read()
+    assert open(tmp_path / "direct.h5", "rb").read() == want
+    assert open(tmp_path / "behind.h5", "rb").read() == want
+    assert log and all(ev.is_set() for ev in log)                # every held buffer was given back
+    st = GenotypeStore(str(tmp_path / "direct.h5"))
+    assert st.groups() == ["chr_3", "chr_5", "chr_9"] and st.meta["groups"]["chr_9"]["n_variants"] == 4000
+    assert st.meta["groups"]["chr_5"]["n_chunks"] == 0
+    st.close()
