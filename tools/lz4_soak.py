@@ -102,7 +102,7 @@ def main():
     rng = np.random.default_rng(2026)
     lo = 1.0 / 5008
     total = same = handed = 0
-    for clevel, depth in ((1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 12)):
+    for clevel, depth in ((1, 0), (3, 1), (5, 2), (7, 4), (8, 8), (9, 12 | 0x100)):   # (clevel 9: twelve candidates + the lazy rule)
         for scale in (0.01, 0.1, 0.5, 1.0, 2.0, 4.0, 8.0):
             p = np.minimum(lo * (0.5 / lo) ** rng.random((per, N)) * scale, 0.5)
             planes = (rng.random((per, N)) < p).astype(np.uint8)
